@@ -1,0 +1,521 @@
+// api.hip -- host side of libmipt: the C-ABI declared in include/mipt.h.
+//
+// Owns all HIP state (one device + one stream per tracer handle), flattens scenes into the traversal layout and
+// drives the wavefront integrator.  Replaces, for the hot path only: CUDATracerProg::Trace
+// (CUDATracer/CUDATracerProg/CUDATracerProg.cu:937-963), CUDAScene::CUDAScene (CUDATracer/CUDATracer.hpp:133-203)
+// and CUDABuffer (CUDATracer/CUDABuffer.cpp:111-224).
+#include "../../include/mipt.h"
+#include "bvh_builder.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace mipt;
+
+struct mipt_tracer {
+    int device = 0;
+    int numCU = 256;
+    hipStream_t own = nullptr, stream = nullptr;
+    std::string err;
+    // options
+    int64_t tilePixels = 0;          // 0 = derive from queueBudgetMB
+    int64_t queueBudgetMB = 6144;
+    int64_t rngMode = MIPT_RNG_NODE;
+    int64_t countPixelRays = 0;
+    int64_t blocksPerCU = 8;
+    // work buffers
+    Queue q[2] = {};
+    size_t qcap[2] = { 0, 0 };
+    uint32_t* counts = nullptr;               // per-level queue counters
+    unsigned long long* stats = nullptr;      // [0] rays
+    float* sample = nullptr; size_t samplePixels = 0;
+    uint32_t* pixelRays = nullptr; size_t pixelRaysCap = 0;
+    // counters
+    uint64_t frames = 0, launches = 0; double kernelMs = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct mipt_scene {
+    mipt_tracer* t = nullptr;
+    SceneDev dev = {};
+    void* dNodes = nullptr; void* dRefs = nullptr; void* dShade = nullptr; void* dMats = nullptr; void* dEnv = nullptr;
+    std::vector<float> hNodes, hRefs;    // host copies for mipt_scene_get_bvh
+    uint32_t nTris = 0;
+};
+
+struct mipt_buffer {
+    mipt_tracer* t = nullptr;
+    void* cpu = nullptr; void* gpu = nullptr; size_t size = 0; int head = MIPT_HEAD_UNINITIALIZED;
+};
+
+namespace {
+
+int fail(mipt_tracer* t, int code, const std::string& msg) { if (t) t->err = msg; return code; }
+#define HIPCHK(t, call)                                                                                   \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((t), MIPT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+int use(mipt_tracer* t) { hipError_t e = hipSetDevice(t->device); if (e != hipSuccess) return fail(t, MIPT_E_HIP, "hipSetDevice failed"); return MIPT_OK; }
+
+void free_queue(Queue& q) { if (q.a) hipFree(q.a); if (q.b) hipFree(q.b); if (q.c) hipFree(q.c); q = Queue{}; }
+
+int ensure_queue(mipt_tracer* t, int which, size_t cap) {
+    if (t->qcap[which] >= cap) return MIPT_OK;
+    free_queue(t->q[which]); t->qcap[which] = 0;
+    if (cap == 0) return MIPT_OK;
+    HIPCHK(t, hipMalloc((void**)&t->q[which].a, cap * sizeof(float4)));
+    HIPCHK(t, hipMalloc((void**)&t->q[which].b, cap * sizeof(float4)));
+    HIPCHK(t, hipMalloc((void**)&t->q[which].c, cap * sizeof(float4)));
+    t->qcap[which] = cap;
+    return MIPT_OK;
+}
+
+void resolve_events(mipt_tracer* t) {
+    for (auto& p : t->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) t->kernelMs += ms;
+        hipEventDestroy(p.first); hipEventDestroy(p.second);
+    }
+    t->pending.clear();
+}
+
+// per-frame camera constants: RTProgram::GenRay, CUDATracerProg.cu:369-397
+FrameDev make_frame(const mipt_settings& s, uint32_t frameID) {
+    FrameDev F;
+    memcpy(F.camPos, s.cam.pos, 12); memcpy(F.front, s.cam.front, 12); memcpy(F.right, s.cam.right, 12); memcpy(F.up, s.cam.up, 12);
+    float num_x = (float)s.viewportWidth, num_y = (float)s.viewportHeight;
+    float edgeLen = std::min(num_x, num_y);
+    float fovScale = atanf(s.cam.fov / 2);                       // (sic) atan, CUDATracerProg.cu:389
+    F.pixelSize = (float)(1.0 / edgeLen * fovScale * 2);
+    float w = num_x * F.pixelSize, h = num_y * F.pixelSize;
+    F.originX = -w / 2; F.originY = -h / 2;
+    F.W = s.viewportWidth; F.H = s.viewportHeight; F.frameID = frameID; F.maxDepth = s.maxDepth;
+    return F;
+}
+
+inline float hdot(const float* a, const float* b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------------
+int mipt_create(int device, mipt_tracer** out) {
+    if (!out) return MIPT_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MIPT_E_NODEVICE;
+    if (device < 0 || device >= n) return MIPT_E_INVALID;
+    mipt_tracer* t = new mipt_tracer();
+    t->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete t; return MIPT_E_HIP; }
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) t->numCU = cu;
+    if (hipStreamCreateWithFlags(&t->own, hipStreamNonBlocking) != hipSuccess) { delete t; return MIPT_E_HIP; }
+    t->stream = t->own;
+    if (hipMalloc((void**)&t->counts, 64 * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&t->stats, 8 * sizeof(unsigned long long)) != hipSuccess) {
+        mipt_destroy(t); return MIPT_E_NOMEM;
+    }
+    hipMemsetAsync(t->stats, 0, 8 * sizeof(unsigned long long), t->stream);
+    hipStreamSynchronize(t->stream);
+    *out = t;
+    return MIPT_OK;
+}
+
+void mipt_destroy(mipt_tracer* t) {
+    if (!t) return;
+    hipSetDevice(t->device);
+    if (t->stream) hipStreamSynchronize(t->stream);
+    resolve_events(t);
+    free_queue(t->q[0]); free_queue(t->q[1]);
+    if (t->counts) hipFree(t->counts);
+    if (t->stats) hipFree(t->stats);
+    if (t->sample) hipFree(t->sample);
+    if (t->pixelRays) hipFree(t->pixelRays);
+    if (t->own) hipStreamDestroy(t->own);
+    delete t;
+}
+
+const char* mipt_last_error(const mipt_tracer* t) { return t ? t->err.c_str() : "null tracer"; }
+
+int mipt_set_stream(mipt_tracer* t, void* s) { if (!t) return MIPT_E_INVALID; t->stream = s ? (hipStream_t)s : t->own; return MIPT_OK; }
+
+int mipt_synchronize(mipt_tracer* t) {
+    if (!t) return MIPT_E_INVALID;
+    if (use(t)) return MIPT_E_HIP;
+    HIPCHK(t, hipStreamSynchronize(t->stream));
+    resolve_events(t);
+    return MIPT_OK;
+}
+
+int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
+    if (!t || !key) return MIPT_E_INVALID;
+    std::string k(key);
+    if (k == "tile_pixels") { if (v < 0) return fail(t, MIPT_E_INVALID, "tile_pixels < 0"); t->tilePixels = v; }
+    else if (k == "queue_budget_mb") { if (v < 1) return fail(t, MIPT_E_INVALID, "queue_budget_mb < 1"); t->queueBudgetMB = v; }
+    else if (k == "rng_mode") { if (v != MIPT_RNG_NODE && v != MIPT_RNG_DFS) return fail(t, MIPT_E_INVALID, "bad rng_mode"); t->rngMode = v; }
+    else if (k == "count_pixel_rays") t->countPixelRays = v ? 1 : 0;
+    else if (k == "blocks_per_cu") { if (v < 1 || v > 32) return fail(t, MIPT_E_INVALID, "blocks_per_cu out of range"); t->blocksPerCU = v; }
+    else return fail(t, MIPT_E_INVALID, "unknown option " + k);
+    return MIPT_OK;
+}
+
+int mipt_get_counters(mipt_tracer* t, mipt_counters* out) {
+    if (!t || !out) return MIPT_E_INVALID;
+    int rc = mipt_synchronize(t); if (rc) return rc;
+    unsigned long long rays = 0;
+    HIPCHK(t, hipMemcpy(&rays, t->stats, sizeof rays, hipMemcpyDeviceToHost));
+    out->rays = rays; out->frames = t->frames; out->kernel_ms = t->kernelMs; out->launches = t->launches;
+    return MIPT_OK;
+}
+
+int mipt_reset_counters(mipt_tracer* t) {
+    if (!t) return MIPT_E_INVALID;
+    int rc = mipt_synchronize(t); if (rc) return rc;
+    HIPCHK(t, hipMemsetAsync(t->stats, 0, 8 * sizeof(unsigned long long), t->stream));
+    HIPCHK(t, hipStreamSynchronize(t->stream));
+    t->frames = 0; t->launches = 0; t->kernelMs = 0;
+    return MIPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Scene upload.  One flat, aligned buffer per stream (nodes / refs / shading / materials / env map) instead of the
+// reference's per-node cudaMemcpy walk (CUDATracer.hpp:99-129).
+// ---------------------------------------------------------------------------------------------------------------
+int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out) {
+    if (!d || !out) return MIPT_E_INVALID;
+    *out = nullptr;
+    if (t && use(t)) return MIPT_E_HIP;     // t == NULL: host-only scene (BVH build + mipt_scene_get_bvh, no upload)
+    if (d->meshCnt && !d->meshes) return fail(t, MIPT_E_INVALID, "meshes is null");
+    std::vector<TriPos> tris;
+    std::vector<uint32_t> triMesh;
+    std::vector<float> shade;     // 12 per triangle
+    for (uint32_t m = 0; m < d->meshCnt; m++) {
+        const mipt_mesh_desc& md = d->meshes[m];
+        if (md.indicesCnt % 3) return fail(t, MIPT_E_INVALID, "indicesCnt is not a multiple of 3");
+        if (md.indicesCnt && (!md.indices || !md.vertices)) return fail(t, MIPT_E_INVALID, "mesh arrays are null");
+        for (uint32_t i = 0; i < md.indicesCnt; i += 3) {
+            TriPos tp; float nn[3][3];
+            for (int k = 0; k < 3; k++) {
+                uint32_t vi = md.indices[i + k];
+                if (vi >= md.vertexCnt) return fail(t, MIPT_E_INVALID, "vertex index out of range");
+                memcpy(tp.v[k], md.vertices[vi].position, 12);
+                // unit vertex normal, as the reference normalises at hit time (CUDATracerProg.cu:290-293)
+                const float* n = md.vertices[vi].normal;
+                float len = sqrtf(hdot(n, n));
+                for (int a = 0; a < 3; a++) nn[k][a] = (n[a] * 1.f) / len;
+            }
+            tris.push_back(tp); triMesh.push_back(m);
+            float rec[12] = { nn[0][0], nn[0][1], nn[0][2], 0, nn[1][0], nn[1][1], nn[1][2], 0, nn[2][0], nn[2][1], nn[2][2], 0 };
+            memcpy(&rec[3], &m, 4);
+            shade.insert(shade.end(), rec, rec + 12);
+        }
+    }
+    BvhParams bp;
+    bp.builder = d->bvhBuilder;
+    if (bp.builder != MIPT_BVH_SBVH && bp.builder != MIPT_BVH_MEDIAN) return fail(t, MIPT_E_INVALID, "unknown bvhBuilder");
+    if (d->maxLeafSize) bp.maxLeafSize = d->maxLeafSize;
+    if (d->splitAlpha > 0.f) bp.splitAlpha = d->splitAlpha;
+    BvhOut bo;
+    std::string berr = build_bvh(tris, bp, bo);
+    if (!berr.empty()) return fail(t, MIPT_E_LIMIT, "BVH build: " + berr);
+
+    mipt_scene* s = new mipt_scene();
+    s->t = t; s->nTris = (uint32_t)tris.size();
+    s->hNodes = std::move(bo.nodes);
+    s->hRefs.resize(bo.refTri.size() * 12);
+    for (size_t r = 0; r < bo.refTri.size(); r++) {
+        uint32_t g = bo.refTri[r]; const TriPos& tp = tris[g];
+        float* R = &s->hRefs[r * 12];
+        for (int a = 0; a < 3; a++) { R[a] = tp.v[0][a]; R[4 + a] = tp.v[1][a] - tp.v[0][a]; R[8 + a] = tp.v[2][a] - tp.v[0][a]; }
+        memcpy(&R[3], &g, 4); memcpy(&R[7], &triMesh[g], 4); R[11] = 0.f;
+    }
+    std::vector<float> mats((size_t)std::max<uint32_t>(d->meshCnt, 1) * 12, 0.f);
+    for (uint32_t m = 0; m < d->meshCnt; m++) {
+        const mipt_material& mm = d->meshes[m].material; float* M = &mats[(size_t)m * 12];
+        M[0] = mm.color[0]; M[1] = mm.color[1]; M[2] = mm.color[2]; M[3] = mm.roughness;
+        M[4] = mm.metallic; M[5] = mm.opacity; M[6] = mm.n; M[7] = mm.emissiveStrength;
+        M[8] = mm.emissiveColor[0]; M[9] = mm.emissiveColor[1]; M[10] = mm.emissiveColor[2]; M[11] = 0.f;
+    }
+    auto upload = [&](void** dst, const void* src, size_t bytes) -> bool {
+        if (bytes == 0) bytes = 16;
+        if (hipMalloc(dst, bytes) != hipSuccess) return false;
+        if (src && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return false;
+        return true;
+    };
+    if (shade.empty()) shade.resize(12, 0.f);
+    if (s->hRefs.empty()) s->hRefs.resize(12, 0.f);
+    if (t) {
+        bool ok = upload(&s->dNodes, s->hNodes.data(), s->hNodes.size() * 4) && upload(&s->dRefs, s->hRefs.data(), s->hRefs.size() * 4) &&
+                  upload(&s->dShade, shade.data(), shade.size() * 4) && upload(&s->dMats, mats.data(), mats.size() * 4);
+        if (ok && d->envMap && d->envW && d->envH) ok = upload(&s->dEnv, d->envMap, (size_t)d->envW * d->envH * 3 * 4);
+        if (!ok) { mipt_scene_destroy(s); return fail(t, MIPT_E_NOMEM, "scene upload failed"); }
+    }
+    if (bo.refTri.empty()) s->hRefs.clear();
+    s->dev.nodes = (const float4*)s->dNodes; s->dev.refs = (const float4*)s->dRefs; s->dev.shade = (const float4*)s->dShade;
+    s->dev.mats = (const float4*)s->dMats; s->dev.env = (const float*)s->dEnv;
+    s->dev.envW = s->dEnv ? d->envW : 0; s->dev.envH = s->dEnv ? d->envH : 0;
+    memcpy(s->dev.skyColor, d->sky.color, 12); memcpy(s->dev.skyDir, d->sky.dir, 12); s->dev.skyIntensity = d->sky.intensity;
+    s->dev.nNodes = (uint32_t)(s->hNodes.size() / 16); s->dev.nRefs = (uint32_t)bo.refTri.size();
+    if (t) hipDeviceSynchronize();
+    *out = s;
+    return MIPT_OK;
+}
+
+void mipt_scene_destroy(mipt_scene* s) {
+    if (!s) return;
+    if (s->t) hipSetDevice(s->t->device);
+    if (s->dNodes) hipFree(s->dNodes);
+    if (s->dRefs) hipFree(s->dRefs);
+    if (s->dShade) hipFree(s->dShade);
+    if (s->dMats) hipFree(s->dMats);
+    if (s->dEnv) hipFree(s->dEnv);
+    delete s;
+}
+
+int mipt_scene_get_bvh(const mipt_scene* s, float* nodes, uint32_t* n_nodes, float* refs, uint32_t* n_refs) {
+    if (!s) return MIPT_E_INVALID;
+    if (n_nodes) *n_nodes = (uint32_t)(s->hNodes.size() / 16);
+    if (n_refs) *n_refs = (uint32_t)(s->hRefs.size() / 12);
+    if (nodes) memcpy(nodes, s->hNodes.data(), s->hNodes.size() * 4);
+    if (refs) memcpy(refs, s->hRefs.data(), s->hRefs.size() * 4);
+    return MIPT_OK;
+}
+uint32_t mipt_scene_triangle_count(const mipt_scene* s) { return s ? s->nTris : 0; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The hot path
+// ---------------------------------------------------------------------------------------------------------------
+int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_t first_frame, uint32_t n_frames,
+                uint32_t frame_stride, int sum_mode, float* acc_dev, unsigned char* ldr_dev) {
+    if (!t || !sc || !st || !acc_dev) return fail(t, MIPT_E_INVALID, "null argument");
+    if (sc->t != t) return fail(t, MIPT_E_INVALID, "scene belongs to another tracer");
+    if (use(t)) return MIPT_E_HIP;
+    const uint32_t W = st->viewportWidth, H = st->viewportHeight, D = st->maxDepth;
+    if (!W || !H) return fail(t, MIPT_E_INVALID, "empty viewport");
+    if ((uint64_t)W * H >= (1ull << 31)) return fail(t, MIPT_E_LIMIT, "viewport too large");
+    if (D > 30) return fail(t, MIPT_E_LIMIT, "maxDepth > 30 (node ids are 32-bit)");
+    if (t->rngMode == MIPT_RNG_DFS) return fail(t, MIPT_E_INVALID, "rng_mode dfs is not available in this build");
+    if (frame_stride == 0) frame_stride = 1;
+    const uint32_t npix = W * H;
+
+    if (t->samplePixels < npix) {
+        if (t->sample) hipFree(t->sample);
+        t->sample = nullptr; t->samplePixels = 0;
+        HIPCHK(t, hipMalloc((void**)&t->sample, (size_t)npix * 16));
+        t->samplePixels = npix;
+    }
+    if (t->countPixelRays && t->pixelRaysCap < npix) {
+        if (t->pixelRays) hipFree(t->pixelRays);
+        t->pixelRays = nullptr; t->pixelRaysCap = 0;
+        HIPCHK(t, hipMalloc((void**)&t->pixelRays, (size_t)npix * 4));
+        t->pixelRaysCap = npix;
+    }
+    // tile size: rays at level k <= tile * 2^k; the two ping-pong queues hold the largest odd / even level
+    uint32_t tile = npix;
+    if (D >= 2) {
+        uint64_t maxEntries = (uint64_t)t->queueBudgetMB * 1024 * 1024 / 48;
+        uint64_t perPixel = (1ull << (D - 1)) + (D >= 3 ? (1ull << (D - 2)) : 0);
+        uint64_t fit = maxEntries / perPixel;
+        if (t->tilePixels > 0) fit = (uint64_t)t->tilePixels;
+        if (fit < 64) return fail(t, MIPT_E_LIMIT, "queue budget too small for this maxDepth");
+        if (fit < tile) tile = (uint32_t)fit;
+        if (tile >= 256) tile &= ~255u;
+        if (((uint64_t)tile << (D - 1)) >= (1ull << 32)) return fail(t, MIPT_E_LIMIT, "tile * 2^(maxDepth-1) exceeds 32-bit queue indices");
+        uint32_t oddMax = ((D - 1) & 1) ? (D - 1) : (D - 2);          // largest odd level <= D-1 (>= 1)
+        uint32_t evenMax = ((D - 1) & 1) ? (D - 2) : (D - 1);         // largest even level <= D-1 (may be 0 -> unused)
+        int rc = ensure_queue(t, 1, (size_t)tile << oddMax); if (rc) return rc;
+        if (evenMax >= 2) { rc = ensure_queue(t, 0, (size_t)tile << evenMax); if (rc) return rc; }
+    }
+    const int persistentBlocks = t->numCU * (int)t->blocksPerCU;
+
+    hipEvent_t ev0, ev1;
+    HIPCHK(t, hipEventCreate(&ev0)); HIPCHK(t, hipEventCreate(&ev1));
+    HIPCHK(t, hipEventRecord(ev0, t->stream));
+    for (uint32_t fi = 0; fi < n_frames; fi++) {
+        const uint32_t frame = first_frame + fi * frame_stride;
+        HIPCHK(t, hipMemsetAsync(t->sample, 0, (size_t)npix * 16, t->stream));
+        if (t->countPixelRays) HIPCHK(t, hipMemsetAsync(t->pixelRays, 0, (size_t)npix * 4, t->stream));
+        LevelArgs A;
+        A.S = sc->dev; A.F = make_frame(*st, frame);
+        A.sample = t->sample; A.pixelRays = t->countPixelRays ? t->pixelRays : nullptr; A.stats = t->stats;
+        for (uint32_t p0 = 0; p0 < npix; p0 += tile) {
+            const uint32_t np = std::min(tile, npix - p0);
+            HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), t->stream));
+            A.pix0 = p0; A.npix = np;
+            for (uint32_t k = 0; k < D; k++) {
+                A.level = k;
+                A.qin = t->q[k & 1]; A.qout = t->q[(k + 1) & 1];
+                A.inCount = t->counts + k; A.outCount = t->counts + k + 1;
+                int blocks = k == 0 ? std::min<int>((int)((np + 255) / 256), persistentBlocks) : persistentBlocks;
+                launch_level(A, k == 0, blocks, t->stream);
+                t->launches++;
+            }
+        }
+        const float weight = (float)(1.0 / (frame + 1.0));       // CUDATracerProg.cu:878
+        launch_accumulate(t->sample, acc_dev, ldr_dev, weight, sum_mode, 0, npix, t->stream);
+        t->frames++;
+    }
+    HIPCHK(t, hipEventRecord(ev1, t->stream));
+    t->pending.emplace_back(ev0, ev1);
+    HIPCHK(t, hipGetLastError());
+    if (t->pending.size() > 256) resolve_events(t);
+    return MIPT_OK;
+}
+
+int mipt_trace(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, float* acc_dev, unsigned char* ldr_dev) {
+    if (!st) return fail(t, MIPT_E_INVALID, "null settings");
+    return mipt_render(t, sc, st, st->frameID, 1, 1, 0, acc_dev, ldr_dev);
+}
+
+int mipt_tonemap(mipt_tracer* t, const float* acc_dev, float scale, uint32_t n_pixels, unsigned char* ldr_dev) {
+    if (!t || !acc_dev || !ldr_dev) return fail(t, MIPT_E_INVALID, "null argument");
+    if (use(t)) return MIPT_E_HIP;
+    launch_tonemap(acc_dev, scale, n_pixels, ldr_dev, t->stream);
+    HIPCHK(t, hipGetLastError());
+    return MIPT_OK;
+}
+
+int mipt_last_sample(mipt_tracer* t, float* rgb_host, uint32_t* rays_host, uint32_t n_pixels) {
+    if (!t) return MIPT_E_INVALID;
+    if (use(t)) return MIPT_E_HIP;
+    if (n_pixels > t->samplePixels) return fail(t, MIPT_E_INVALID, "no sample of that size");
+    HIPCHK(t, hipStreamSynchronize(t->stream));
+    if (rgb_host) {
+        std::vector<float> tmp((size_t)n_pixels * 4);
+        HIPCHK(t, hipMemcpy(tmp.data(), t->sample, tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n_pixels; i++) { rgb_host[i * 3] = tmp[i * 4]; rgb_host[i * 3 + 1] = tmp[i * 4 + 1]; rgb_host[i * 3 + 2] = tmp[i * 4 + 2]; }
+    }
+    if (rays_host) {
+        if (!t->pixelRays || t->pixelRaysCap < n_pixels) return fail(t, MIPT_E_INVALID, "count_pixel_rays was not enabled");
+        HIPCHK(t, hipMemcpy(rays_host, t->pixelRays, (size_t)n_pixels * 4, hipMemcpyDeviceToHost));
+    }
+    return MIPT_OK;
+}
+
+int mipt_trace_rays(mipt_tracer* t, mipt_scene* sc, const float* o, const float* d, uint32_t n, mipt_hit* hits) {
+    if (!t || !sc || (n && (!o || !d || !hits))) return fail(t, MIPT_E_INVALID, "null argument");
+    if (sc->t != t) return fail(t, MIPT_E_INVALID, "scene belongs to another tracer");
+    if (use(t)) return MIPT_E_HIP;
+    launch_trace_rays(sc->dev, o, d, n, hits, t->stream);
+    HIPCHK(t, hipGetLastError());
+    return MIPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device buffer layer (CUDABuffer's lazy host/device mirror; first touch is zero-filled, CUDABuffer.cpp:114-118,140-145)
+// ---------------------------------------------------------------------------------------------------------------
+int mipt_buffer_create(mipt_tracer* t, size_t size, mipt_buffer** out) {
+    if (!t || !out) return MIPT_E_INVALID;
+    mipt_buffer* b = new mipt_buffer(); b->t = t; b->size = size; *out = b;
+    return MIPT_OK;
+}
+void mipt_buffer_destroy(mipt_buffer* b) {
+    if (!b) return;
+    hipSetDevice(b->t->device);
+    if (b->cpu) hipHostFree(b->cpu);
+    if (b->gpu) hipFree(b->gpu);
+    delete b;
+}
+static bool buf_to_cpu(mipt_buffer* b) {
+    hipSetDevice(b->t->device);
+    size_t sz = b->size ? b->size : 1;
+    switch (b->head) {
+        case MIPT_HEAD_UNINITIALIZED:
+            if (hipHostMalloc(&b->cpu, sz, hipHostMallocDefault) != hipSuccess) return false;
+            memset(b->cpu, 0, sz); b->head = MIPT_HEAD_AT_CPU; break;
+        case MIPT_HEAD_AT_GPU:
+            if (!b->cpu && hipHostMalloc(&b->cpu, sz, hipHostMallocDefault) != hipSuccess) return false;
+            // blocking copy ordered after the tracer's stream, as the reference's default-stream cudaMemcpy is
+            if (hipStreamSynchronize(b->t->stream) != hipSuccess) return false;
+            if (hipMemcpy(b->cpu, b->gpu, b->size, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            b->head = MIPT_HEAD_SYNCED; break;
+        default: break;
+    }
+    return true;
+}
+static bool buf_to_gpu(mipt_buffer* b) {
+    hipSetDevice(b->t->device);
+    size_t sz = b->size ? b->size : 1;
+    switch (b->head) {
+        case MIPT_HEAD_UNINITIALIZED:
+            if (hipMalloc(&b->gpu, sz) != hipSuccess) return false;
+            if (hipMemsetAsync(b->gpu, 0, sz, b->t->stream) != hipSuccess) return false;
+            if (hipStreamSynchronize(b->t->stream) != hipSuccess) return false;
+            b->head = MIPT_HEAD_AT_GPU; break;
+        case MIPT_HEAD_AT_CPU:
+            if (!b->gpu && hipMalloc(&b->gpu, sz) != hipSuccess) return false;
+            if (hipStreamSynchronize(b->t->stream) != hipSuccess) return false;
+            if (hipMemcpy(b->gpu, b->cpu, b->size, hipMemcpyHostToDevice) != hipSuccess) return false;
+            b->head = MIPT_HEAD_SYNCED; break;
+        default: break;
+    }
+    return true;
+}
+const void* mipt_buffer_cpu_data(mipt_buffer* b) { if (!b || !buf_to_cpu(b)) return nullptr; return b->cpu; }
+const void* mipt_buffer_gpu_data(mipt_buffer* b) { if (!b || !buf_to_gpu(b)) return nullptr; return b->gpu; }
+void* mipt_buffer_mutable_cpu_data(mipt_buffer* b) { if (!b || !buf_to_cpu(b)) return nullptr; b->head = MIPT_HEAD_AT_CPU; return b->cpu; }
+void* mipt_buffer_mutable_gpu_data(mipt_buffer* b) { if (!b || !buf_to_gpu(b)) return nullptr; b->head = MIPT_HEAD_AT_GPU; return b->gpu; }
+int mipt_buffer_head(const mipt_buffer* b) { return b ? b->head : MIPT_E_INVALID; }
+size_t mipt_buffer_size(const mipt_buffer* b) { return b ? b->size : 0; }
+int mipt_buffer_async_gpu_push(mipt_buffer* b) {
+    if (!b || b->head != MIPT_HEAD_AT_CPU) return MIPT_E_INVALID;
+    mipt_tracer* t = b->t;
+    if (use(t)) return MIPT_E_HIP;
+    if (!b->gpu) HIPCHK(t, hipMalloc(&b->gpu, b->size ? b->size : 1));
+    HIPCHK(t, hipMemcpyAsync(b->gpu, b->cpu, b->size, hipMemcpyHostToDevice, t->stream));
+    b->head = MIPT_HEAD_SYNCED;
+    return MIPT_OK;
+}
+
+int mipt_malloc(mipt_tracer* t, size_t size, void** dev_out) {
+    if (!t || !dev_out) return MIPT_E_INVALID;
+    if (use(t)) return MIPT_E_HIP;
+    HIPCHK(t, hipMalloc(dev_out, size ? size : 1));
+    return MIPT_OK;
+}
+int mipt_free(mipt_tracer* t, void* dev) { if (!t) return MIPT_E_INVALID; if (use(t)) return MIPT_E_HIP; if (dev) HIPCHK(t, hipFree(dev)); return MIPT_OK; }
+int mipt_upload(mipt_tracer* t, void* dev, const void* host, size_t size) {
+    if (!t || (size && (!dev || !host))) return MIPT_E_INVALID;
+    if (use(t)) return MIPT_E_HIP;
+    HIPCHK(t, hipStreamSynchronize(t->stream));
+    if (size) HIPCHK(t, hipMemcpy(dev, host, size, hipMemcpyHostToDevice));
+    return MIPT_OK;
+}
+int mipt_download(mipt_tracer* t, void* host, const void* dev, size_t size) {
+    if (!t || (size && (!dev || !host))) return MIPT_E_INVALID;
+    if (use(t)) return MIPT_E_HIP;
+    HIPCHK(t, hipStreamSynchronize(t->stream));
+    if (size) HIPCHK(t, hipMemcpy(host, dev, size, hipMemcpyDeviceToHost));
+    return MIPT_OK;
+}
+int mipt_memset(mipt_tracer* t, void* dev, int value, size_t size) {
+    if (!t || (size && !dev)) return MIPT_E_INVALID;
+    if (use(t)) return MIPT_E_HIP;
+    if (size) HIPCHK(t, hipMemsetAsync(dev, value, size, t->stream));
+    return MIPT_OK;
+}
+
+int mipt_test_math(mipt_tracer* t, int fn, const float* a, const float* b, uint32_t n, float* out) {
+    if (!t || !a || !out) return MIPT_E_INVALID;
+    if (use(t)) return MIPT_E_HIP;
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    size_t bytes = (size_t)std::max<uint32_t>(n, 1) * 4;
+    HIPCHK(t, hipMalloc((void**)&da, bytes)); HIPCHK(t, hipMalloc((void**)&db, bytes)); HIPCHK(t, hipMalloc((void**)&dout, bytes));
+    HIPCHK(t, hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (b) HIPCHK(t, hipMemcpy(db, b, (size_t)n * 4, hipMemcpyHostToDevice)); else HIPCHK(t, hipMemset(db, 0, bytes));
+    launch_test_math(fn, da, db, n, dout, t->stream);
+    HIPCHK(t, hipStreamSynchronize(t->stream));
+    HIPCHK(t, hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dout);
+    return MIPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// bvh_builder.h -- host BVH builders that emit the GPU traversal layout directly.
+//
+// Layout (also documented in include/mipt.h):
+//   node  = 16 floats: [c0.min xyz][c0.max xyz][c1.min xyz][c1.max xyz][ref0][ref1][0][0]
+//   ref   = uint32: bit31 set -> leaf, bits 27..30 = reference count (<= 15), bits 0..26 = first reference;
+//           bit31 clear -> index of an inner node.  Node 0 is the root and is always an inner node.
+//   refTri[i] = global triangle id of reference i (a triangle may be referenced by several leaves: spatial splits).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mipt {
+
+struct TriPos { float v[3][3]; };   // three vertex positions
+
+struct BvhParams {
+    uint32_t builder = 0;        // 0 SBVH, 1 median
+    uint32_t maxLeafSize = 4;    // <= 15
+    float    splitAlpha = 1.0e-5f;   // SplitBVHBuilder.hpp:67
+    // SAH constants: the reference's `Platform` is undeclared; pinned here as in NVIDIA's default Platform.
+    float    nodeCost = 1.0f;    // getNodeCost(n) = nodeCost * n
+    float    triCost = 1.0f;     // getTriangleCost(n) = triCost * n
+    uint32_t minLeafSize = 1;
+};
+
+struct BvhOut {
+    std::vector<float>    nodes;     // 16 per node
+    std::vector<uint32_t> refTri;    // per reference
+    uint32_t maxDepth = 0;           // deepest inner-node level (root = 0)
+    uint32_t duplicates = 0;         // references - triangles
+};
+
+constexpr uint32_t kMaxBvhDepth = 64;       // traversal stack capacity on the device
+constexpr uint32_t kLeafFlag = 0x80000000u;
+inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return kLeafFlag | (count << 27) | first; }
+
+// returns empty string on success, otherwise an error message
+std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOut& out);
+
+}  // namespace mipt

@@ -1,0 +1,61 @@
+// kernels.h -- device-side data layout and launch wrappers shared by api.hip and kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mipt {
+
+// Scene as the kernels see it.  Everything is flat, 16-byte aligned float4 streams in HBM:
+//   nodes : 4 x float4 per BVH2 node (both children's boxes + two child refs)     64 B
+//   refs  : 3 x float4 per triangle reference (v0|triId, e1|meshId, e2|0)          48 B
+//   shade : 3 x float4 per triangle (unit vertex normals n0|meshId, n1, n2)        48 B, touched only for the winning hit
+//   mats  : 3 x float4 per mesh (color|roughness, metallic opacity n emissiveStrength, emissiveColor|0)
+struct SceneDev {
+    const float4* nodes;
+    const float4* refs;
+    const float4* shade;
+    const float4* mats;
+    const float*  env;        // float RGB rows, or nullptr
+    uint32_t envW, envH;
+    float skyColor[3]; float skyDir[3]; float skyIntensity;
+    uint32_t nNodes, nRefs;
+};
+
+// Per-frame constants computed once on the host (CUDATracerProg.cu:369-397 computes them per thread).
+struct FrameDev {
+    float camPos[3], front[3], right[3], up[3];
+    float pixelSize, originX, originY;
+    uint32_t W, H, frameID, maxDepth;
+};
+
+// Ray queue, structure of arrays of float4 so that a wave reads/writes 1 KiB per instruction:
+//   a = (o.x o.y o.z d.x)  b = (d.y d.z beta.r beta.g)  c = (beta.b, pixel, node, s0)
+struct Queue { float4* a; float4* b; float4* c; };
+
+struct LevelArgs {
+    SceneDev S; FrameDev F;
+    Queue qin, qout;
+    const uint32_t* inCount;     // rays in qin (ignored for the primary level)
+    uint32_t* outCount;          // rays appended to qout
+    float* sample;               // per-pixel radiance of this frame, 4 floats per pixel (rgb + unused)
+    uint32_t* pixelRays;         // optional per-pixel ray counter (tests), may be nullptr
+    unsigned long long* stats;   // [0] rays traced
+    uint32_t level;              // depth of the rays in qin (0 = primary)
+    uint32_t pix0, npix;         // pixel tile handled by this pass
+};
+
+struct DfsArgs {
+    SceneDev S; FrameDev F;
+    float* sample; uint32_t* pixelRays; unsigned long long* stats;
+    uint32_t pix0, npix;
+};
+
+void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s);
+void launch_dfs(const DfsArgs& a, int blocks, hipStream_t s);
+void launch_accumulate(const float* sample, float* acc, unsigned char* ldr, float weight, int sumMode,
+                       uint32_t pix0, uint32_t npix, hipStream_t s);
+void launch_tonemap(const float* acc, float scale, uint32_t npix, unsigned char* ldr, hipStream_t s);
+void launch_trace_rays(const SceneDev& S, const float* o, const float* d, uint32_t n, void* hits, hipStream_t s);
+void launch_test_math(int fn, const float* a, const float* b, uint32_t n, float* out, hipStream_t s);
+
+}  // namespace mipt

@@ -1,0 +1,421 @@
+// kernels.hip -- gfx950 kernels of the path-tracing core.
+//
+// Replaces the reference's single megakernel `GenRay` (CUDATracer/CUDATracerProg/CUDATracerProg.cu:859-922) with a
+// wavefront integrator: one launch per recursion level, each lane traces one queued ray through the flat BVH2,
+// shades the hit and appends up to two child rays to the next level's queue with a wave64 ballot/prefix compaction
+// (one atomic per wave).  Radiance is carried top-down as a throughput weight, so no return values flow back up
+// the recursion tree (the reference's recursion, CUDATracerProg.cu:426-541, is linear in the children's radiance).
+//
+// Per-function reference lines are cited inline.  Arithmetic contract: see device_math.h.
+#include "kernels.h"
+#include "device_math.h"
+
+#include <float.h>
+
+namespace mipt {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kLeaf = 0x80000000u;
+constexpr uint32_t kTerm = 0xFFFFFFFFu;
+constexpr int kStackCap = 64;      // == kMaxBvhDepth of the builder
+constexpr int kLdsStack = 16;      // entries per lane kept in LDS; deeper entries spill to scratch
+
+struct HitRec { float t, u, v; int ref; int tri; bool front; };   // ref = reference index, tri = global triangle id
+
+struct RayPre { v3 o, d, idir, ood; };
+
+// CUDATracerProg.cu:567-574
+MIPT_DEV RayPre ray_pre(v3 o, v3 d) {
+    const float ooeps = 8.271806125530277e-25f;   // exp2f(-80)
+    RayPre r; r.o = o; r.d = d;
+    r.idir.x = 1.0f / (__builtin_fabsf(d.x) > ooeps ? d.x : __builtin_copysignf(ooeps, d.x));
+    r.idir.y = 1.0f / (__builtin_fabsf(d.y) > ooeps ? d.y : __builtin_copysignf(ooeps, d.y));
+    r.idir.z = 1.0f / (__builtin_fabsf(d.z) > ooeps ? d.z : __builtin_copysignf(ooeps, d.z));
+    r.ood = mk3(o.x * r.idir.x, o.y * r.idir.y, o.z * r.idir.z);
+    return r;
+}
+
+// slab test: CUDATracerProg.cu:651-658 + spanBegin/EndKepler (:86-87) -> v_min3/v_max3 on gfx950
+MIPT_DEV bool slab(const RayPre& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float hitT, float& tnear) {
+    float lox = ffma(mnx, r.idir.x, -r.ood.x), hix = ffma(mxx, r.idir.x, -r.ood.x);
+    float loy = ffma(mny, r.idir.y, -r.ood.y), hiy = ffma(mxy, r.idir.y, -r.ood.y);
+    float loz = ffma(mnz, r.idir.z, -r.ood.z), hiz = ffma(mxz, r.idir.z, -r.ood.z);
+    float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lox, hix), __builtin_fminf(loy, hiy)),
+                                 __builtin_fmaxf(__builtin_fminf(loz, hiz), 0.0f));
+    float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lox, hix), __builtin_fmaxf(loy, hiy)),
+                                 __builtin_fminf(__builtin_fmaxf(loz, hiz), hitT));
+    tnear = tmin;
+    return tmin <= tmax;
+}
+
+// Moller-Trumbore on a precomputed (v0, e1, e2) reference: CUDATracerProg.cu:232-263.  Strict t < tmin as in the
+// reference; an exact tie goes to the lower global triangle id (the reference lets the first triangle found win, which
+// across meshes is the lower mesh index), so the closest hit does not depend on the BVH's shape.
+MIPT_DEV bool mt_test(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, int id, int bestId, float& t_, float& u_, float& v_, bool& front) {
+    v3 pvec = cross3(d, e2);
+    float det = dot3(e1, pvec);
+    if (__builtin_fabsf(det) < FLT_EPSILON) return false;
+    float invDet = 1 / det;
+    v3 tvec = o - v0;
+    float u = dot3(tvec, pvec) * invDet;
+    if (u < 0 || u > 1) return false;
+    v3 qvec = cross3(tvec, e1);
+    float v = dot3(d, qvec) * invDet;
+    if (v < 0 || u + v > 1) return false;
+    float t = dot3(e2, qvec) * invDet;
+    if (t > 0 && (t < tmin || (t == tmin && id < bestId))) { t_ = t; u_ = u; v_ = v; front = det > 0; return true; }
+    return false;
+}
+
+// Traversal stack: the first kLdsStack entries of every lane live in LDS (bank = lane, conflict-free), deeper
+// entries in a private scratch array that is only touched by unusually deep paths.
+struct Stack {
+    uint32_t* lds;                 // &block_lds[threadIdx.x]
+    uint32_t deep[kStackCap - kLdsStack];
+    int sp;
+    MIPT_DEV void push(uint32_t x) {
+        if (sp < kLdsStack) lds[sp * kBlock] = x; else deep[sp - kLdsStack] = x;
+        sp++;
+    }
+    MIPT_DEV uint32_t pop() {
+        sp--;
+        return sp < kLdsStack ? lds[sp * kBlock] : deep[sp - kLdsStack];
+    }
+};
+
+// Closest hit (TraceRay, CUDATracerProg.cu:543-794) on the flat scene BVH.  Near child first, far child pushed;
+// leaves are tested when they become current; hitT shrinks as hits are found and culls later box tests.
+MIPT_DEV HitRec traverse(const SceneDev& S, v3 o, v3 d, uint32_t* ldsStack) {
+    RayPre r = ray_pre(o, d);
+    HitRec h; h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
+    Stack st; st.lds = ldsStack; st.sp = 0;
+    st.push(kTerm);
+    uint32_t cur = 0;
+    while (true) {
+        while (!(cur & kLeaf)) {
+            const float4* N = S.nodes + (size_t)cur * 4;
+            float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+            float t0, t1;
+            bool h0 = slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, h.t, t0);
+            bool h1 = slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, h.t, t1);
+            uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
+            if (h0 || h1) {
+                uint32_t first = h0 ? c0 : c1;
+                if (h0 && h1) {
+                    uint32_t second = c1;
+                    if (t1 < t0) { first = c1; second = c0; }
+                    st.push(second);
+                }
+                cur = first;
+            } else {
+                cur = st.pop();
+            }
+        }
+        if (cur == kTerm) break;
+        uint32_t cnt = (cur >> 27) & 0xFu, first = cur & 0x07FFFFFFu;
+        for (uint32_t i = first; i < first + cnt; i++) {
+            const float4* T = S.refs + (size_t)i * 3;
+            float4 a = T[0], b = T[1], c = T[2];
+            float tt, uu, vv; bool ff;
+            int id = (int)__float_as_uint(a.w);
+            if (mt_test(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) { h.t = tt; h.u = uu; h.v = vv; h.front = ff; h.ref = (int)i; h.tri = id; }
+        }
+        cur = st.pop();
+    }
+    return h;
+}
+
+// ---- sampling (CUDATracerProg.cu:93-180) --------------------------------------------------------------------
+MIPT_DEV void cone_basis(v3 dir, v3& right, v3& up) {
+    float rx = dir.z, ry = -dir.x;
+    float rlen = __builtin_sqrtf(0.f + rx * rx + ry * ry);
+    right = rlen <= 0 ? mk3(0, 0, 1) : mk3(rx, 0, ry) / rlen;
+    up = cross3(right, dir);
+}
+MIPT_DEV v3 rand_dir_inside_cone(Lcg& rng, v3 dir, float size) {
+    v3 right, up; cone_basis(dir, right, up);
+    float u = rng.NextFloat(), v = rng.NextFloat();
+    float theta = (float)(6.283185307179586 * (double)u);
+    float sx = 1 - 2 * v * size;
+    float sn, cs; det_sincosf(theta, &sn, &cs);
+    float sy = __builtin_sqrtf(1 - sx * sx) * cs;
+    float sz = __builtin_sqrtf(1 - sx * sx) * sn;
+    return sx * dir + sy * up + sz * right;
+}
+MIPT_DEV v3 ggx_rand_dir_inside_cone(Lcg& rng, v3 dir, float size) {
+    v3 right, up; cone_basis(dir, right, up);
+    float u = rng.NextFloat(), v = rng.NextFloat();
+    float theta = (float)(6.283185307179586 * (double)u);
+    float phi = det_atan2f(size * __builtin_sqrtf(v), __builtin_sqrtf(1 - v));
+    float sp, cp; det_sincosf(phi, &sp, &cp);
+    float sx = 1 - sp;                                        // (sic) CUDATracerProg.cu:160
+    float sn, cs; det_sincosf(theta, &sn, &cs);
+    float sy = __builtin_sqrtf(1 - sx * sx) * cs;
+    float sz = __builtin_sqrtf(1 - sx * sx) * sn;
+    return sx * dir + sy * up + sz * right;
+}
+
+// ---- miss (OnMiss, CUDATracerProg.cu:796-846) ------------------------------------------------------------------
+MIPT_DEV v3 on_miss(const SceneDev& S, v3 d) {
+    if (S.env == nullptr) {
+        v3 sd = mk3(S.skyDir[0], S.skyDir[1], S.skyDir[2]);
+        float ang = (1 - dot3(d, sd)) / 2;
+        return mk3(S.skyColor[0], S.skyColor[1], S.skyColor[2]) * S.skyIntensity * pow10_mul(ang);
+    }
+    float dy = __builtin_fminf(1.0f, __builtin_fmaxf(-1.0f, d.y));
+    float zenith = det_acosf(dy);
+    float azimuth = det_atan2f(d.x, d.z);
+    float v = (float)((double)zenith / 3.14159265358979323846);
+    float u = (float)((double)azimuth / (3.14159265358979323846 * 2) + 0.5);
+    u *= (float)S.envW; v *= (float)S.envH;
+    int u0 = (int)u, v0 = (int)v;
+    int uc = min(max(u0, 0), (int)S.envW - 1), vc = min(max(v0, 0), (int)S.envH - 1);
+    uint32_t a = (uint32_t)vc * S.envW + (uint32_t)uc;
+    const float* px = S.env + (size_t)a * 3;
+    v3 p00 = mk3(px[0], px[1], px[2]);
+    float du = u - u0, dv = v - v0;
+    v3 p0 = (dv) * p00 + (1 - dv) * p00;
+    v3 p1 = (dv) * p00 + (1 - dv) * p00;
+    return du * p1 + (1 - du) * p0;
+}
+
+struct Material { v3 color; float roughness, metallic, opacity, n, emissiveStrength; v3 emissive; };
+MIPT_DEV Material load_material(const SceneDev& S, uint32_t mesh) {
+    const float4* M = S.mats + (size_t)mesh * 3;
+    float4 a = M[0], b = M[1], c = M[2];
+    Material m; m.color = xyz(a); m.roughness = a.w; m.metallic = b.x; m.opacity = b.y; m.n = b.z; m.emissiveStrength = b.w; m.emissive = xyz(c);
+    return m;
+}
+
+// Surface frame at the hit (tail of NearestIntersectSubset, CUDATracerProg.cu:268-294)
+struct Surface { v3 P, N; uint32_t mesh; };
+MIPT_DEV Surface surface_at(const SceneDev& S, v3 o, v3 d, const HitRec& h) {
+    const float4* Sh = S.shade + (size_t)h.tri * 3;
+    float4 s0 = Sh[0], s1 = Sh[1], s2 = Sh[2];
+    float w0 = 1 - h.u - h.v, w1 = h.u, w2 = h.v;
+    v3 hn = xyz(s0) * w0 + xyz(s1) * w1 + xyz(s2) * w2;
+    Surface sf; sf.P = o + d * h.t; sf.N = h.front ? hn : -hn; sf.mesh = __float_as_uint(s0.w);
+    return sf;
+}
+
+// One bounce of LaunchRayRecur (CUDATracerProg.cu:439-528), top-down: given the incoming ray and the hit, produce the
+// two child rays and the factors their radiance is multiplied by.  `rng` supplies GGX (2) then diffuse (2) draws.
+struct Bounce { v3 o1, d1, f1; v3 o2, d2, f2; v3 emit; };
+MIPT_DEV Bounce shade_hit(const Material& mat, const Surface& sf, v3 d, bool front, Lcg& rng) {
+    Bounce b;
+    v3 N = sf.N, P = sf.P;
+    v3 mN = ggx_rand_dir_inside_cone(rng, N, mat.roughness);
+    v3 R = reflect3(d, mN);
+    b.o1 = P + N * 1e-6f; b.d1 = R;
+    float n1 = 1.f, n2 = mat.n; n2 += FLT_EPSILON;
+    if (!front) { float t = n1; n1 = n2; n2 = t; }
+    float r0 = (n1 - n2) / (n1 + n2); r0 *= r0;
+    float rr = (1 - dot3(-d, mN));
+    rr = pow5_mul(rr);
+    rr = r0 + (1 - r0) * rr;
+    rr = saturatef(rr);
+    rr = mat.metallic * 1.f + (1 - mat.metallic) * rr;
+    float rt = 1 - rr;
+    v3 absorb = mat.metallic * mat.color + (1 - mat.metallic) * mk3(1.f, 1.f, 1.f);
+    b.f1 = absorb * rr;
+    if (mat.opacity < 1.f) {
+        v3 frontv = (d + R) / 2.0f;
+        v3 down = d - frontv;
+        float down_len = length3(down);
+        down = down_len < 1e-10f ? mk3(1, 0, 0) : (down / down_len);
+        v3 front_refr = frontv * (n1 / n2);
+        float frl = length3(front_refr);
+        if (frl > 1) frl = 1;
+        float drl = __builtin_sqrtf(1 - frl * frl);
+        b.d2 = normalize3(front_refr + down * drl);
+        b.o2 = P - N * 1e-6f;
+    } else {
+        b.d2 = rand_dir_inside_cone(rng, N, 0.49f);
+        b.o2 = P + N * 1e-6f;
+    }
+    b.f2 = mat.color * rt * ((mat.opacity == 1.f) ? 1.f : (1 - mat.opacity));
+    b.emit = mat.emissive * mat.emissiveStrength;
+    return b;
+}
+
+// Primary ray (RTProgram::GenRay, CUDATracerProg.cu:367-417)
+MIPT_DEV void gen_primary(const FrameDev& F, uint32_t pix, v3& o, v3& d, uint32_t& s0) {
+    uint32_t i = pix % F.W, j = pix / F.W;
+    Lcg rng; rng.state = tea16(pix, F.frameID);      // local_seed = w*j + i (:373); settings.seed unused (:374)
+    s0 = rng.state;
+    float offx = rng.NextFloat() * F.pixelSize;
+    float offy = rng.NextFloat() * F.pixelSize;
+    float u = ((float)(int)i * F.pixelSize + F.originX + offx);
+    float v = ((float)(int)j * F.pixelSize + F.originY + offy);
+    v3 dir = mk3(F.front[0], F.front[1], F.front[2]) + mk3(F.right[0], F.right[1], F.right[2]) * u + mk3(F.up[0], F.up[1], F.up[2]) * v;
+    d = normalize3(dir);
+    o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
+}
+
+MIPT_DEV void add_sample(float* sample, uint32_t pix, v3 c) {
+    float* p = sample + (size_t)pix * 4;
+    if (c.x != 0.f) unsafeAtomicAdd(p + 0, c.x);
+    if (c.y != 0.f) unsafeAtomicAdd(p + 1, c.y);
+    if (c.z != 0.f) unsafeAtomicAdd(p + 2, c.z);
+}
+
+// =================================================================================================================
+// Wavefront level kernel.  Persistent grid-stride over the input queue; every lane handles one ray per iteration.
+// =================================================================================================================
+template <bool PRIMARY>
+__global__ void __launch_bounds__(kBlock) k_level(LevelArgs A) {
+    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    const uint32_t n = PRIMARY ? A.npix : *A.inCount;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(A.stats, (unsigned long long)n);
+    const bool spawn = A.level + 1 < A.F.maxDepth;            // children have ttl-1 > 0 (CUDATracerProg.cu:433)
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += stride) {
+        const uint32_t idx = base + threadIdx.x;
+        const bool active = idx < n;
+        v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), beta = mk3(1.f, 1.f, 1.f);
+        uint32_t pix = 0, node = 1, s0 = 0;
+        bool has1 = false, has2 = false;
+        Bounce b;
+        if (active) {
+            if (PRIMARY) {
+                pix = A.pix0 + idx;
+                gen_primary(A.F, pix, o, d, s0);
+            } else {
+                float4 qa = A.qin.a[idx], qb = A.qin.b[idx], qc = A.qin.c[idx];
+                o = xyz(qa); d = mk3(qa.w, qb.x, qb.y); beta = mk3(qb.z, qb.w, qc.x);
+                pix = __float_as_uint(qc.y); node = __float_as_uint(qc.z); s0 = __float_as_uint(qc.w);
+            }
+            if (A.pixelRays) atomicAdd(A.pixelRays + pix, 1u);
+            HitRec h = traverse(A.S, o, d, ldsStack + threadIdx.x);
+            if (h.ref < 0) {
+                add_sample(A.sample, pix, beta * on_miss(A.S, d));
+            } else {
+                Surface sf = surface_at(A.S, o, d, h);
+                Material mat = load_material(A.S, sf.mesh);
+                v3 emit = mat.emissive * mat.emissiveStrength;
+                add_sample(A.sample, pix, beta * emit);
+                if (spawn) {
+                    Lcg rng; rng.state = node_seed(s0, node);
+                    b = shade_hit(mat, sf, d, h.front, rng);
+                    b.f1 = beta * b.f1; b.f2 = beta * b.f2;
+                    has1 = true; has2 = true;
+                }
+            }
+        }
+        if (spawn) {     // wave-uniform
+            // wave64 compaction: ballot + prefix popcount, one atomic per wave (lane order = ray order is kept)
+            unsigned long long m1 = __ballot(has1), m2 = __ballot(has2);
+            uint32_t total = __popcll(m1) + __popcll(m2);
+            if (total) {
+                uint32_t lane = __lane_id();
+                unsigned long long below = (1ull << lane) - 1ull;
+                uint32_t off = __popcll(m1 & below) + __popcll(m2 & below);
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(A.outCount, total);
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                uint32_t w = wbase + off;
+                if (has1) {
+                    A.qout.a[w] = make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x);
+                    A.qout.b[w] = make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y);
+                    A.qout.c[w] = make_float4(b.f1.z, __uint_as_float(pix), __uint_as_float(node * 2u), __uint_as_float(s0));
+                    w++;
+                }
+                if (has2) {
+                    A.qout.a[w] = make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x);
+                    A.qout.b[w] = make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y);
+                    A.qout.c[w] = make_float4(b.f2.z, __uint_as_float(pix), __uint_as_float(node * 2u + 1u), __uint_as_float(s0));
+                }
+            }
+        }
+    }
+}
+
+void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s) {
+    if (primary) hipLaunchKernelGGL(k_level<true>, dim3(blocks), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL(k_level<false>, dim3(blocks), dim3(kBlock), 0, s, a);
+}
+
+// =================================================================================================================
+// Accumulate + tonemap (tail of GenRay, CUDATracerProg.cu:892-919)
+// =================================================================================================================
+MIPT_DEV unsigned char tonemap1(float x) {
+    x = saturatef(x);
+    x = x / (x + 1.0f);
+    x = det_pow_gamma(x);
+    return (unsigned char)(int)(x * 255);
+}
+__global__ void __launch_bounds__(kBlock) k_accumulate(const float4* sample, float4* acc, uchar4* ldr, float weight, int sumMode,
+                                                        uint32_t pix0, uint32_t npix) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    uint32_t p = pix0 + i;
+    float4 c = sample[p], a = acc[p];
+    float r, g, b;
+    if (sumMode) { r = a.x + c.x; g = a.y + c.y; b = a.z + c.z; }
+    else { r = a.x * (1 - weight) + c.x * weight; g = a.y * (1 - weight) + c.y * weight; b = a.z * (1 - weight) + c.z * weight; }
+    acc[p] = make_float4(r, g, b, 1.f);
+    if (ldr) ldr[p] = make_uchar4(tonemap1(r), tonemap1(g), tonemap1(b), 255);
+}
+void launch_accumulate(const float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, uint32_t pix0, uint32_t npix, hipStream_t s) {
+    if (!npix) return;
+    hipLaunchKernelGGL(k_accumulate, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const float4*)sample, (float4*)acc, (uchar4*)ldr,
+                       weight, sumMode, pix0, npix);
+}
+__global__ void __launch_bounds__(kBlock) k_tonemap(const float4* acc, float scale, uint32_t npix, uchar4* ldr) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    float4 a = acc[i];
+    ldr[i] = make_uchar4(tonemap1(a.x * scale), tonemap1(a.y * scale), tonemap1(a.z * scale), 255);
+}
+void launch_tonemap(const float* acc, float scale, uint32_t npix, unsigned char* ldr, hipStream_t s) {
+    if (!npix) return;
+    hipLaunchKernelGGL(k_tonemap, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const float4*)acc, scale, npix, (uchar4*)ldr);
+}
+
+// =================================================================================================================
+// Closest hit for a caller-supplied ray batch (the traversal kernel on its own)
+// =================================================================================================================
+struct HitOut { float t, u, v; int32_t tri, mesh, front; };
+__global__ void __launch_bounds__(kBlock) k_trace_rays(SceneDev S, const float* o, const float* d, uint32_t n, HitOut* out) {
+    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    v3 ro = mk3(o[(size_t)i * 3], o[(size_t)i * 3 + 1], o[(size_t)i * 3 + 2]);
+    v3 rd = mk3(d[(size_t)i * 3], d[(size_t)i * 3 + 1], d[(size_t)i * 3 + 2]);
+    HitRec h = traverse(S, ro, rd, ldsStack + threadIdx.x);
+    HitOut r; r.t = h.t; r.u = h.u; r.v = h.v; r.front = h.front ? 1 : 0;
+    if (h.ref >= 0) {
+        r.tri = h.tri;
+        r.mesh = (int32_t)__float_as_uint(S.refs[(size_t)h.ref * 3 + 1].w);
+    } else { r.tri = -1; r.mesh = -1; }
+    out[i] = r;
+}
+void launch_trace_rays(const SceneDev& S, const float* o, const float* d, uint32_t n, void* hits, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_trace_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, S, o, d, n, (HitOut*)hits);
+}
+
+// =================================================================================================================
+// Device math self-test
+// =================================================================================================================
+__global__ void k_test_math(int fn, const float* a, const float* b, uint32_t n, float* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s, c, r = 0.f;
+    switch (fn) {
+        case 0: det_sincosf(a[i], &s, &c); r = s; break;
+        case 1: det_sincosf(a[i], &s, &c); r = c; break;
+        case 2: r = det_atan2f(a[i], b[i]); break;
+        case 3: r = det_acosf(a[i]); break;
+        case 4: r = det_pow_gamma(a[i]); break;
+        case 5: r = pow5_mul(a[i]); break;
+        case 6: r = pow10_mul(a[i]); break;
+    }
+    out[i] = r;
+}
+void launch_test_math(int fn, const float* a, const float* b, uint32_t n, float* out, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_test_math, dim3((n + 255) / 256), dim3(256), 0, s, fn, a, b, n, out);
+}
+
+}  // namespace mipt

@@ -1,0 +1,152 @@
+/*
+ * mipt.h -- C-ABI of the MI355X path-tracing core (libmipt.so).
+ *
+ * This is the drop-in boundary for ONE hot path of 0x5b25/CUDAPathTracer: the per-pixel path-tracing integrator
+ * behind `CUDATracer::PathTracer::Trace` (reference CUDATracer/CUDATracer.hpp:352-358, implemented by
+ * CUDATracer/CUDATracerProg/CUDATracerProg.cu:859-963) together with the scene upload it consumes
+ * (`CUDAScene`, CUDATracer.hpp:82-227) and the device buffer layer it is handed (`CUDABuffer`,
+ * CUDATracer/CUDABuffer.hpp:10-45).  Plain pointers and sizes only; every function returns 0 on success or a
+ * negative MIPT_E_* code, and never throws.  The header-only C++ classes in cudapathtracer_amd/cpp/ re-create the
+ * reference's class API (same names) on top of these entry points.
+ *
+ * Threading: a tracer handle owns one GPU and one HIP stream.  Handles are not thread-safe; distinct handles are
+ * independent (one host thread or process per GPU).  All *_dev pointers are device pointers on the tracer's GPU.
+ */
+#ifndef MIPT_H
+#define MIPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- PODs, byte-compatible with the reference (sizes checked in tests) ---------------------------------- */
+typedef struct { float position[3]; float normal[3]; float uv[2]; } mipt_vertex;        /* 32 B  Types.hpp:29-33   */
+typedef struct {
+    float color[3]; float roughness; float metallic; float opacity;
+    float emissiveColor[3]; float emissiveStrength; float n; uint8_t translucent; uint8_t _pad[3];
+} mipt_material;                                                                         /* 48 B  Types.hpp:214-225 */
+typedef struct { float color[3]; float dir[3]; float intensity; } mipt_skylight;        /* 28 B  Types.hpp:227-231 */
+typedef struct { float pos[3]; float front[3]; float up[3]; float right[3]; float fov; } mipt_camera; /* 52 B Types.hpp:20-27 */
+typedef struct {
+    mipt_camera cam; uint32_t viewportWidth, viewportHeight, frameID, seed, maxDepth;
+} mipt_settings;                                                                         /* 72 B  CUDATracer.hpp:11-17 */
+
+typedef struct {
+    const mipt_vertex* vertices; uint32_t vertexCnt;   /* already transformed (Types.hpp:560-574 bakes the matrix) */
+    const uint32_t*    indices;  uint32_t indicesCnt;  /* 3 per triangle */
+    mipt_material      material;
+} mipt_mesh_desc;
+
+enum { MIPT_BVH_SBVH = 0,     /* spatial-split BVH (algorithm of CUDATracer/SplitBVHBuilder.cpp:57-512) */
+       MIPT_BVH_MEDIAN = 1 }; /* median split, leaf <= 4, depth <= 32 (CUDATracer/Types.hpp:312-413), one tree for the scene */
+
+typedef struct {
+    const mipt_mesh_desc* meshes; uint32_t meshCnt;     /* Scene::objects       Types.hpp:427-433 */
+    mipt_skylight sky;                                  /* Scene::skyLight */
+    const float* envMap; uint32_t envW, envH;           /* Scene::envMap / envMapDim: float RGB rows, top row = +Y; NULL = sky */
+    uint32_t bvhBuilder;                                /* MIPT_BVH_* */
+    uint32_t maxLeafSize;                               /* 0 = default (4); at most 15 */
+    float    splitAlpha;                                /* SBVH spatial-split threshold; 0 = reference default 1e-5 */
+} mipt_scene_desc;
+
+typedef struct mipt_tracer mipt_tracer;   /* replaces CUDATracerProg            CUDATracerProg.cu:925-935 */
+typedef struct mipt_scene  mipt_scene;    /* replaces CUDAScene                 CUDATracer.hpp:82-227     */
+typedef struct mipt_buffer mipt_buffer;   /* replaces CUDABuffer                CUDABuffer.hpp:10-45      */
+
+enum { MIPT_OK = 0, MIPT_E_INVALID = -1, MIPT_E_HIP = -2, MIPT_E_NOMEM = -3, MIPT_E_NODEVICE = -4, MIPT_E_LIMIT = -5 };
+
+/* RNG stream order of the integrator */
+enum { MIPT_RNG_NODE = 0,   /* wavefront integrator: stream keyed by the ray's node id in the recursion tree */
+       MIPT_RNG_DFS  = 1 }; /* per-lane depth-first integrator: the reference's single stream per pixel-sample, in its order */
+
+typedef struct {
+    uint64_t rays;          /* closest-hit rays traced since the last reset */
+    uint64_t frames;        /* frames (samples per pixel) rendered */
+    double   kernel_ms;     /* HIP-event time of the integrator kernels */
+    uint64_t launches;      /* integrator kernel launches */
+} mipt_counters;
+
+typedef struct { float t, u, v; int32_t tri; int32_t mesh; int32_t front; } mipt_hit;   /* tri = global triangle id, -1 = miss */
+
+/* ---- tracer: PathTracer ctor/dtor (CUDATracer.cpp:8-148, CUDATracerProg.cu:925-935) ---------------------- */
+int  mipt_create(int device, mipt_tracer** out);
+void mipt_destroy(mipt_tracer*);
+const char* mipt_last_error(const mipt_tracer*);           /* replaces CUDA_CHECK -> __debugbreak (CUDACommon.h:34-54) */
+int  mipt_set_stream(mipt_tracer*, void* hip_stream);      /* NULL = the tracer's own stream */
+int  mipt_synchronize(mipt_tracer*);
+int  mipt_set_option(mipt_tracer*, const char* key, int64_t value);   /* "tile_pixels", "rng_mode", "block" ... */
+int  mipt_get_counters(mipt_tracer*, mipt_counters* out);
+int  mipt_reset_counters(mipt_tracer*);
+
+/* ---- scene upload: CUDAScene::CUDAScene (CUDATracer.hpp:133-203) ------------------------------------------ */
+int  mipt_scene_create(mipt_tracer*, const mipt_scene_desc*, mipt_scene** out);
+void mipt_scene_destroy(mipt_scene*);
+/* flattened traversal data, for inspection/tests: nodes = 16 floats each
+ *   [c0.min xyz][c0.max xyz][c1.min xyz][c1.max xyz][ref0][ref1][0][0]   (ref: bit31 leaf, bits27-30 count, low 27 first; else node index)
+ * refs = 12 floats each [v0 xyz, triId][e1 xyz, meshId][e2 xyz, 0].  Pass NULL buffers to query the counts. */
+int  mipt_scene_get_bvh(const mipt_scene*, float* nodes, uint32_t* n_nodes, float* refs, uint32_t* n_refs);
+uint32_t mipt_scene_triangle_count(const mipt_scene*);
+
+/* ---- the hot path: PathTracer::Trace (CUDATracer.hpp:352-358; CUDATracerProg.cu:937-963) -------------------
+ * One sample per pixel for sample index settings->frameID, folded into acc_dev (w*h*4 floats, running mean with
+ * weight 1/(frameID+1), alpha 1) and tonemapped into ldr_dev (w*h*4 bytes, may be NULL).  Row 0 = bottom.
+ * Asynchronous on the tracer's stream, like the reference's kernel launch. */
+int  mipt_trace(mipt_tracer*, mipt_scene*, const mipt_settings*, float* acc_dev, unsigned char* ldr_dev);
+/* batched form of the same loop (RendererWindow::render called n_frames times, Common/RendererWindow.hpp:128-148):
+ * frames first_frame .. first_frame+n_frames-1; running mean unless sum_mode != 0 (then acc += sample, for
+ * multi-GPU sample striding where the caller reduces and scales). frame_stride lets rank r render r, r+G, ... */
+int  mipt_render(mipt_tracer*, mipt_scene*, const mipt_settings*, uint32_t first_frame, uint32_t n_frames,
+                 uint32_t frame_stride, int sum_mode, float* acc_dev, unsigned char* ldr_dev);
+/* accumulate-free tonemap of an accumulation buffer (scale applied first): CUDATracerProg.cu:908-919 */
+int  mipt_tonemap(mipt_tracer*, const float* acc_dev, float scale, uint32_t n_pixels, unsigned char* ldr_dev);
+/* radiance of the last frame traced, before accumulation (w*h*3 floats) and its per-pixel ray counts; for parity tests */
+int  mipt_last_sample(mipt_tracer*, float* rgb_host, uint32_t* rays_host, uint32_t n_pixels);
+
+/* closest hit for a fixed ray batch (the traversal kernel alone): TraceRay, CUDATracerProg.cu:543-794 */
+int  mipt_trace_rays(mipt_tracer*, mipt_scene*, const float* origins_dev, const float* dirs_dev, uint32_t n,
+                     mipt_hit* hits_dev);
+
+/* ---- device buffer layer: CUDABuffer (CUDABuffer.hpp:10-45, CUDABuffer.cpp:111-224) ------------------------ */
+enum { MIPT_HEAD_UNINITIALIZED = 0, MIPT_HEAD_AT_CPU = 1, MIPT_HEAD_AT_GPU = 2, MIPT_HEAD_SYNCED = 3 };
+int   mipt_buffer_create(mipt_tracer*, size_t size, mipt_buffer** out);
+void  mipt_buffer_destroy(mipt_buffer*);
+const void* mipt_buffer_cpu_data(mipt_buffer*);
+const void* mipt_buffer_gpu_data(mipt_buffer*);
+void* mipt_buffer_mutable_cpu_data(mipt_buffer*);
+void* mipt_buffer_mutable_gpu_data(mipt_buffer*);
+int   mipt_buffer_head(const mipt_buffer*);
+size_t mipt_buffer_size(const mipt_buffer*);
+int   mipt_buffer_async_gpu_push(mipt_buffer*);           /* CUDABuffer::async_gpu_push on the tracer's stream */
+/* raw helpers for callers that manage device memory themselves */
+int   mipt_malloc(mipt_tracer*, size_t size, void** dev_out);
+int   mipt_free(mipt_tracer*, void* dev);
+int   mipt_upload(mipt_tracer*, void* dev, const void* host, size_t size);
+int   mipt_download(mipt_tracer*, void* host, const void* dev, size_t size);
+int   mipt_memset(mipt_tracer*, void* dev, int value, size_t size);
+
+/* ---- callers' scene construction (Types.hpp:435-574; CornellBox/tracer.cpp:16-158; DefaultScene/tracer.cpp:28-123) */
+/* kind 0 quad 1 cube 2 sphere; xform = 16 floats row-major or NULL; returns vertex count, fills up to the caps */
+uint32_t mipt_make_mesh(int kind, const float* xform, mipt_vertex* v, uint32_t vcap, uint32_t* idx, uint32_t icap, uint32_t* icnt);
+/* built-in scenes: 0 Cornell box, 1 DefaultScene */
+uint32_t mipt_builtin_mesh_count(int which);
+uint32_t mipt_builtin_mesh(int which, uint32_t mesh, mipt_vertex* v, uint32_t vcap, uint32_t* idx, uint32_t icap,
+                           uint32_t* icnt, mipt_material* mat);
+void     mipt_builtin_sky(int which, mipt_skylight* sky);
+/* camera basis from (pos, azimuth, zenith, fov): RendererWindow::UpdateCam, Common/RendererWindow.hpp:15-37 */
+void     mipt_make_camera(const float pos[3], float azimuth, float zenith, float fov, mipt_camera* out);
+/* synthetic HDRI stand-in for the missing DefaultScene/sky.hdr (sky gradient + sun disc + value-noise ground) */
+void     mipt_make_synthetic_sky(uint32_t w, uint32_t h, uint32_t seed, float* rgb_out);
+/* synthetic displaced-grid stress mesh (n x n quads, heights = 4-octave value noise): returns vertex count */
+uint32_t mipt_make_grid_mesh(uint32_t n, float extent, float height, uint32_t seed, mipt_vertex* v, uint32_t* idx);
+
+/* ---- device math self-test (used by the parity tests of the portable transcendentals) --------------------- */
+/* fn 0 sin 1 cos 2 atan2(a,b) 3 acos 4 x^(1/2.2) 5 x^5 6 x^10 ; host arrays */
+int  mipt_test_math(mipt_tracer*, int fn, const float* a, const float* b, uint32_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
