@@ -220,6 +220,7 @@ DEFAULT_CAMERA = dict(pos=(-1.0, 1.0, 0.0), azimuth=0.0, zenith=float(np.float32
 class Scene:
     def __init__(self, tracer, data, builder=BVH_SBVH, max_leaf=0, split_alpha=0.0):
         """tracer may be None: host-only scene (BVH build + get_bvh), usable without a GPU."""
+        self.h = None
         self.tracer = tracer
         self.data = data
         desc, keep = data.fill_desc(SceneDesc, MeshDesc)
@@ -249,6 +250,7 @@ class Scene:
 
 class Tracer:
     def __init__(self, device=0):
+        self.h = None
         h = _vp()
         rc = lib.mipt_create(device, C.byref(h))
         if rc != 0:

@@ -1,0 +1,71 @@
+"""The C-ABI library loads, exports every symbol include/mipt.h declares, and its PODs have the reference's sizes."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mipt.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mipt_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(ptlib):
+    syms = declared_symbols()
+    assert len(syms) >= 35
+    missing = [s for s in syms if not hasattr(ptlib.lib, s)]
+    assert not missing, missing
+
+
+def test_pod_sizes_match_reference(ptlib, oracle):
+    # Vertex 32, SurfaceMaterial 48, SkyLight 28, Camera 52, PathTraceSettings 72
+    assert C.sizeof(ptlib.Vertex) == 32 and ptlib.VERTEX_DTYPE.itemsize == 32
+    assert C.sizeof(ptlib.Material) == 48 and ptlib.Material.n.offset == 40 and ptlib.Material.translucent.offset == 44
+    assert C.sizeof(ptlib.SkyLight) == 28
+    assert C.sizeof(ptlib.Camera) == 52
+    assert C.sizeof(ptlib.Settings) == 72 and ptlib.Settings.frameID.offset == 60 and ptlib.Settings.maxDepth.offset == 68
+    assert ptlib.HIT_DTYPE.itemsize == 24
+    for name in ("Material", "SkyLight", "Camera", "Settings", "MeshDesc"):
+        assert C.sizeof(getattr(ptlib, name)) == C.sizeof(getattr(oracle, name)), name
+
+
+def test_product_never_links_the_oracle(ptlib):
+    # the product path must not route through the oracle: libmipt.so has no orc_* symbol and no liboracle dependency
+    import subprocess
+    out = subprocess.run(["nm", "-D", ptlib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "orc_" not in out
+    ldd = subprocess.run(["ldd", ptlib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "liboracle" not in ldd
+    for root, _, files in os.walk(os.path.join(ROOT, "cudapathtracer_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle/" not in src and "liboracle" not in src and "import orc" not in src, f
+
+
+def test_create_fails_loudly_without_gpu(ptlib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(ptlib.MiptError):
+        ptlib.Tracer(0)
+
+
+def test_host_only_scene_errors(ptlib):
+    data = ptlib.builtin_scene(0)
+    v, i, m = data.meshes[0]
+    bad = ptlib.SceneData([(v, i[:5].copy(), m)], data.sky)
+    with pytest.raises(ptlib.MiptError):
+        ptlib.Scene(None, bad)                      # indicesCnt not a multiple of 3
+    i2 = i.copy()
+    i2[0] = 99
+    with pytest.raises(ptlib.MiptError):
+        ptlib.Scene(None, ptlib.SceneData([(v, i2, m)], data.sky))   # vertex index out of range
+    with pytest.raises(ptlib.MiptError):
+        ptlib.Scene(None, data, builder=7)
+    with pytest.raises(ptlib.MiptError):
+        ptlib.Scene(None, data, max_leaf=16)

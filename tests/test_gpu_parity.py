@@ -1,0 +1,294 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libmipt.so) against the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): closest-hit primitive id and t bit-exact on fixed ray batches (ties excepted);
+images at matched spp within a stated tolerance.  Because both sides evaluate the same fp32 expressions, the
+tests ask for more: every hit field bit-exact, per-pixel ray counts identical, radiance within 2e-5 relative
+(the only difference left is the order of fp32 additions into a pixel).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, hits_equal, random_rays, soup_scene
+from test_oracle_kat import ulp_diff
+from test_oracle_render import MG, GOLD, CROP
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5    # per-pixel radiance, relative to max(|expected|, ATOL_FLOOR)
+FLOOR = 1e-3
+
+
+def rel_err(got, exp):
+    return np.abs(got - exp) / np.maximum(np.abs(exp), FLOOR)
+
+
+def dev_buffers(t, w, h, ldr=True):
+    acc = t.malloc(w * h * 16)
+    t.memset(acc, 0, w * h * 16)
+    l = t.malloc(w * h * 4) if ldr else None
+    return acc, l
+
+
+def test_device_math_bit_exact(tracer, oracle):
+    rng = np.random.default_rng(0)
+    n = 1 << 18
+    cases = [(0, rng.uniform(0, 6.2832, n), None), (1, rng.uniform(0, 6.2832, n), None),
+             (2, rng.uniform(-2, 2, n), rng.uniform(-2, 2, n)), (3, rng.uniform(-1, 1, n), None),
+             (4, rng.uniform(0, 1, n), None), (5, rng.uniform(0, 2, n), None), (6, rng.uniform(0, 1, n), None),
+             (2, np.array([0, 0, 1, -1, 1e-30, 5], np.float32), np.array([0, -1, 0, 0, 1e30, 0], np.float32)),
+             (3, np.array([1, -1, 0.5, -0.5, 0, 0.9999999], np.float32), None), (4, np.array([0, 1e-31, 1e-20, 0.5, 1], np.float32), None)]
+    for fn, a, b in cases:
+        a = np.asarray(a, np.float32)
+        b = None if b is None else np.asarray(b, np.float32)
+        g = tracer.test_math(fn, a, b)
+        c = oracle.math_eval(fn, oracle.MATH_DET, a, b)
+        assert np.array_equal(g.view(np.uint32), c.view(np.uint32)), fn
+
+
+@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("scene", ["cornell", "default", "soup"])
+def test_closest_hit_bit_exact(tracer, ptlib, oracle, builder, scene):
+    data = {"cornell": lambda: ptlib.builtin_scene(0), "default": lambda: ptlib.builtin_scene(1),
+            "soup": lambda: soup_scene(20000, 5)}[scene]()
+    sc = ptlib.Scene(tracer, data, builder=builder)
+    o = oracle.Scene(data)
+    o.set_flat_bvh(*sc.bvh())
+    og, dg = random_rays(300000, 17)
+    g = tracer.trace_rays(sc, og, dg)
+    c, _ = o.trace_rays(oracle.ISECT_FLAT, og, dg, nthreads=16)
+    assert hits_equal(g, c) == 0
+    assert (c["tri"] >= 0).sum() > 1000
+    # axis-aligned and degenerate directions (idir guard, CUDATracerProg.cu:568-571)
+    ax = np.array([(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1), (0.6, 0.8, 0), (0, -0.6, 0.8)], np.float32)
+    o2 = np.tile(np.array([(0.1, 0.2, 0.3)], np.float32), (len(ax), 1))
+    assert hits_equal(tracer.trace_rays(sc, o2, ax), o.trace_rays(oracle.ISECT_FLAT, o2, ax)[0]) == 0
+    # empty batch
+    assert len(tracer.trace_rays(sc, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))) == 0
+
+
+@pytest.mark.parametrize("name", ["cornell", "default"])
+def test_golden_rays(tracer, ptlib, name):
+    # committed fixture: brute-force closest hits from the oracle; the BVH path must reproduce primitive id and t
+    g = np.load(os.path.join(GOLD, f"rays_{name}.npz"))
+    sc = ptlib.Scene(tracer, MG.scene_data(name))
+    h = tracer.trace_rays(sc, g["origins"], g["dirs"])
+    exp = g["hits"]
+    bad = np.nonzero((h["tri"] != exp["tri"]) | (h["t"].view(np.uint32) != exp["t"].view(np.uint32)))[0]
+    assert len(bad) <= 8, len(bad)      # ties excepted: rays that start inside a box see its bottom coplanar with the floor
+    assert (ulp_diff(h["t"][bad], exp["t"][bad]) <= 4).all()
+    ok = np.setdiff1d(np.arange(len(exp)), bad)
+    assert hits_equal(h[ok], exp[ok]) == 0
+
+
+@pytest.mark.parametrize("name", ["cornell", "default"])
+def test_golden_render_crop(tracer, ptlib, oracle, name):
+    which, cam_kw, env, depth, frames = MG.CONFIGS[name]
+    sc = ptlib.Scene(tracer, MG.scene_data(name))
+    s = ptlib.make_settings(ptlib.make_camera(**cam_kw), 256, 256, depth)
+    acc, ldr = dev_buffers(tracer, 256, 256)
+    tracer.render(sc, s, 0, frames, acc, ldr)
+    a = tracer.download(acc, (256, 256, 4), np.float32)
+    l = tracer.download(ldr, (256, 256, 4), np.uint8)
+    tracer.free(acc), tracer.free(ldr)
+    g = np.load(os.path.join(GOLD, f"render_{name}_node_det.npz"))
+    x0, y0, x1, y1 = CROP
+    assert rel_err(a[y0:y1, x0:x1], g["acc"]).max() < RTOL * 4      # 8-16 frames of running mean
+    assert np.abs(l[y0:y1, x0:x1].astype(int) - g["ldr"].astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("name,w,h,depth", [("cornell", 160, 96, 5), ("default", 128, 128, 7), ("cornell", 67, 33, 1), ("default", 64, 64, 12)])
+def test_frame_matches_oracle(tracer, ptlib, oracle, name, w, h, depth):
+    which, cam_kw, env, _, _ = MG.CONFIGS[name]
+    data = MG.scene_data(name)
+    sc = ptlib.Scene(tracer, data)
+    o = oracle.Scene(data)
+    o.set_flat_bvh(*sc.bvh())
+    s = ptlib.make_settings(ptlib.make_camera(**cam_kw), w, h, depth)
+    acc, ldr = dev_buffers(tracer, w, h)
+    tracer.set_option("count_pixel_rays", 1)
+    tracer.reset_counters()
+    try:
+        exp_acc = np.zeros((h, w, 4), np.float32)
+        for frame in (0, 1, 5):      # running mean continues from whatever acc holds, like the reference
+            s.frameID = frame
+            tracer.trace(sc, s, acc, ldr)
+            rgb, rays = tracer.last_sample(w * h, rays=True)
+            r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, frame, 1, acc=exp_acc, nthreads=16)
+            assert np.array_equal(rays.reshape(h, w), r["rays"]), frame          # identical ray trees
+            assert rel_err(rgb.reshape(h, w, 3), r["sample"]).max() < RTOL, frame
+            a = tracer.download(acc, (h, w, 4), np.float32)
+            assert rel_err(a, r["acc"]).max() < RTOL and (a[..., 3] == 1).all()
+            l = tracer.download(ldr, (h, w, 4), np.uint8)
+            assert np.abs(l.astype(int) - r["ldr"].astype(int)).max() <= 1 and (l != r["ldr"]).mean() < 1e-3
+            assert l[..., :3].max() <= 186 and (l[..., 3] == 255).all()
+        assert tracer.counters().frames == 3
+    finally:
+        tracer.set_option("count_pixel_rays", 0)
+        tracer.free(acc), tracer.free(ldr)
+
+
+def test_env_map_lookup(tracer, ptlib, oracle):
+    # an open scene: every path ends in an env-map texel (OnMiss, CUDATracerProg.cu:809-844), incl. poles and seam
+    env = ptlib.synthetic_sky(128, 64, 7)
+    v = np.zeros(3, ptlib.VERTEX_DTYPE)
+    v["position"] = [(100, 100, 100), (100, 100, 101), (101, 100, 101)]
+    v["normal"] = (0, 1, 0)
+    sky = ptlib.SkyLight()
+    data = ptlib.SceneData([(v, np.arange(3, dtype=np.uint32), ptlib.make_material())], sky, env)
+    sc = ptlib.Scene(tracer, data)
+    o = oracle.Scene(data)
+    o.set_flat_bvh(*sc.bvh())
+    for zen in (0.0, 1.3, float(np.float32(np.pi))):
+        cam = ptlib.make_camera((0, 0, 0), 2.0, zen, 1.0)
+        s = ptlib.make_settings(cam, 96, 64, 3)
+        acc, _ = dev_buffers(tracer, 96, 64, ldr=False)
+        tracer.render(sc, s, 0, 1, acc)
+        rgb = tracer.last_sample(96 * 64)
+        tracer.free(acc)
+        r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, 1)
+        assert np.array_equal(rgb.reshape(64, 96, 3), r["sample"])     # one contribution per pixel: exact
+
+
+def test_render_batch_equals_trace_loop(tracer, ptlib):
+    sc = ptlib.Scene(tracer, ptlib.builtin_scene(0))
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), 128, 72, 4)
+    acc1, _ = dev_buffers(tracer, 128, 72, ldr=False)
+    acc2, _ = dev_buffers(tracer, 128, 72, ldr=False)
+    tracer.render(sc, s, 0, 6, acc1)
+    for f in range(6):                   # RendererWindow::render loop: Trace, then the CALLER bumps frameID
+        s.frameID = f
+        tracer.trace(sc, s, acc2, None)
+    a1, a2 = tracer.download(acc1, (72, 128, 4), np.float32), tracer.download(acc2, (72, 128, 4), np.float32)
+    assert rel_err(a1, a2).max() < RTOL
+    # sum mode with a stride: what rank r of G renders; the sum over ranks / N equals the running mean
+    total = np.zeros((72, 128, 4), np.float32)
+    for r in range(2):
+        tracer.memset(acc2, 0, 128 * 72 * 16)
+        tracer.render(sc, s, r, 3, acc2, None, frame_stride=2, sum_mode=1)
+        total += tracer.download(acc2, (72, 128, 4), np.float32)
+    assert rel_err(total[..., :3] / 6, a1[..., :3]).max() < 1e-4
+    tracer.free(acc1), tracer.free(acc2)
+
+
+def test_tile_size_does_not_change_the_image(tracer, ptlib):
+    sc = ptlib.Scene(tracer, ptlib.builtin_scene(1, ptlib.synthetic_sky(64, 32)))
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.DEFAULT_CAMERA), 200, 120, 6)
+    acc, _ = dev_buffers(tracer, 200, 120, ldr=False)
+    out = []
+    try:
+        for tile in (0, 4096, 777, 64):
+            tracer.set_option("tile_pixels", tile)
+            tracer.reset_counters()
+            tracer.render(sc, s, 3, 1, acc)
+            out.append((tracer.last_sample(200 * 120), tracer.counters().rays))
+    finally:
+        tracer.set_option("tile_pixels", 0)
+        tracer.free(acc)
+    for rgb, rays in out[1:]:
+        assert rays == out[0][1] and rel_err(rgb, out[0][0]).max() < RTOL
+
+
+def test_full_size_properties_1080p(tracer, ptlib, oracle):
+    """BASELINE config C2's shape (Cornell 1920x1080, 8 bounces), size-independent properties plus an oracle spot check."""
+    w, h, depth = 1920, 1080, 8
+    data = ptlib.builtin_scene(0)
+    sc = ptlib.Scene(tracer, data)
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), w, h, depth)
+    acc, ldr = dev_buffers(tracer, w, h)
+    tracer.set_option("count_pixel_rays", 1)
+    try:
+        tracer.reset_counters()
+        tracer.render(sc, s, 2, 1, acc, ldr)
+        rgb, rays = tracer.last_sample(w * h, rays=True)
+        assert tracer.counters().rays == int(rays.sum(dtype=np.uint64))          # conservation: queue totals == per-pixel totals
+        assert rays.min() >= 1 and rays.max() <= 2 ** depth - 1 and (rays % 2 == 1).all()   # full binary trees are odd
+        assert np.isfinite(rgb).all() and rgb.min() >= 0
+        # idempotence: the same frame again gives the same sample (up to atomic-add order)
+        tracer.render(sc, s, 2, 1, acc, ldr)
+        rgb2, rays2 = tracer.last_sample(w * h, rays=True)
+        assert np.array_equal(rays, rays2) and rel_err(rgb2, rgb).max() < RTOL
+        l = tracer.download(ldr, (h, w, 4), np.uint8)
+        assert l[..., :3].max() <= 186 and (l[..., 3] == 255).all()
+        # oracle spot check on three rows of the full-size frame
+        o = oracle.Scene(data)
+        o.set_flat_bvh(*sc.bvh())
+        rgb = rgb.reshape(h, w, 3)
+        for y in (0, 517, 1079):
+            r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 2, 1, rect=(0, y, w, y + 1), nthreads=16)
+            assert np.array_equal(rays.reshape(h, w)[y], r["rays"][y])
+            assert rel_err(rgb[y], r["sample"][y]).max() < RTOL
+    finally:
+        tracer.set_option("count_pixel_rays", 0)
+        tracer.free(acc), tracer.free(ldr)
+
+
+def test_tonemap_entry_point(tracer, ptlib, oracle):
+    rng = np.random.default_rng(5)
+    a = rng.uniform(0, 3, (4096, 4)).astype(np.float32)
+    d = tracer.malloc(a.nbytes)
+    l = tracer.malloc(4096 * 4)
+    tracer.upload(d, a)
+    tracer.tonemap(d, 0.5, 4096, l)
+    out = tracer.download(l, (4096, 4), np.uint8)
+    x = np.clip(a[:, :3] * np.float32(0.5), 0, 1)
+    x = (x / (x + 1)).astype(np.float32)
+    exp = (oracle.math_eval(4, oracle.MATH_DET, x.reshape(-1)) * np.float32(255)).astype(np.int32).reshape(-1, 3)
+    assert np.array_equal(out[:, :3], exp) and (out[:, 3] == 255).all()
+    tracer.free(d), tracer.free(l)
+
+
+def test_error_behaviour(tracer, ptlib):
+    import ctypes as C
+    sc = ptlib.Scene(tracer, ptlib.builtin_scene(0))
+    cam = ptlib.make_camera(**ptlib.CORNELL_CAMERA)
+    acc, _ = dev_buffers(tracer, 16, 16, ldr=False)
+    with pytest.raises(ptlib.MiptError):
+        tracer.render(sc, ptlib.make_settings(cam, 0, 16, 4), 0, 1, acc)          # empty viewport
+    with pytest.raises(ptlib.MiptError):
+        tracer.render(sc, ptlib.make_settings(cam, 16, 16, 31), 0, 1, acc)        # node ids are 32-bit
+    with pytest.raises(ptlib.MiptError):
+        tracer.render(sc, ptlib.make_settings(cam, 16, 16, 4), 0, 1, None)        # null accumulation buffer
+    with pytest.raises(ptlib.MiptError):
+        tracer.set_option("no_such_option", 1)
+    assert "unknown option" in tracer.last_error()
+    host_only = ptlib.Scene(None, ptlib.builtin_scene(0))
+    with pytest.raises(ptlib.MiptError):
+        tracer.render(host_only, ptlib.make_settings(cam, 16, 16, 4), 0, 1, acc)  # scene of another (no) tracer
+    h = C.c_void_p()
+    assert ptlib.lib.mipt_create(9999, C.byref(h)) != 0 and not h.value
+    # maxDepth 0: nothing traced, black frame
+    tracer.reset_counters()
+    tracer.render(sc, ptlib.make_settings(cam, 16, 16, 0), 0, 1, acc)
+    assert tracer.counters().rays == 0 and not tracer.last_sample(256).any()
+    tracer.free(acc)
+
+
+def test_device_buffer_layer(tracer, ptlib):
+    """CUDABuffer semantics (CUDABuffer.cpp:111-224): lazy mirrors, zero-filled first touch, head state machine."""
+    import ctypes as C
+    lib = ptlib.lib
+    b = C.c_void_p()
+    assert lib.mipt_buffer_create(tracer.h, 4096, C.byref(b)) == 0
+    assert lib.mipt_buffer_head(b) == 0 and lib.mipt_buffer_size(b) == 4096            # UNINITIALIZED
+    g = lib.mipt_buffer_mutable_gpu_data(b)
+    assert g and lib.mipt_buffer_head(b) == 2                                           # HEAD_AT_GPU
+    assert not tracer.download(g, 4096, np.uint8).any()                                 # zero-filled device memory
+    tracer.memset(g, 0x5A, 4096)
+    cpu = lib.mipt_buffer_cpu_data(b)                                                   # blocking D2H, like bitmap->cpu_data()
+    assert lib.mipt_buffer_head(b) == 3                                                 # SYNCED
+    assert (np.ctypeslib.as_array(C.cast(cpu, C.POINTER(C.c_uint8)), (4096,)) == 0x5A).all()
+    m = lib.mipt_buffer_mutable_cpu_data(b)
+    assert lib.mipt_buffer_head(b) == 1                                                 # HEAD_AT_CPU
+    np.ctypeslib.as_array(C.cast(m, C.POINTER(C.c_uint8)), (4096,))[:] = 7
+    g2 = lib.mipt_buffer_gpu_data(b)                                                    # H2D on demand
+    assert g2 == g and lib.mipt_buffer_head(b) == 3 and (tracer.download(g2, 4096, np.uint8) == 7).all()
+    lib.mipt_buffer_destroy(b)
+    b2 = C.c_void_p()
+    lib.mipt_buffer_create(tracer.h, 64, C.byref(b2))
+    c = lib.mipt_buffer_cpu_data(b2)
+    assert lib.mipt_buffer_head(b2) == 1 and not np.ctypeslib.as_array(C.cast(c, C.POINTER(C.c_uint8)), (64,)).any()
+    assert lib.mipt_buffer_async_gpu_push(b2) == 0 and lib.mipt_buffer_head(b2) == 3
+    tracer.synchronize()
+    lib.mipt_buffer_destroy(b2)

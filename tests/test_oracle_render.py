@@ -1,0 +1,114 @@
+"""The oracle's integrator: regression against the committed golden crops, agreement between its own modes
+(intersector backends, RNG orders, math tables) and the reference's accumulate/tonemap semantics."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+CROP = (112, 112, 144, 144)
+
+
+def load_cfg():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+MG = load_cfg()
+
+
+@pytest.mark.parametrize("name", ["cornell", "default"])
+def test_golden_render_regression(ptlib, oracle, name):
+    which, cam_kw, env, depth, frames = MG.CONFIGS[name]
+    o = oracle.Scene(MG.scene_data(name))
+    s = ptlib.make_settings(ptlib.make_camera(**cam_kw), 256, 256, depth)
+    x0, y0, x1, y1 = CROP
+    g = np.load(os.path.join(GOLD, f"render_{name}_node_det.npz"))
+    r = o.render(s, oracle.ISECT_BRUTE, oracle.RNG_NODE, oracle.MATH_DET, 0, frames, rect=CROP)
+    assert np.array_equal(r["acc"][y0:y1, x0:x1], g["acc"])           # portable math: bit-exact everywhere
+    assert np.array_equal(r["ldr"][y0:y1, x0:x1], g["ldr"]) and r["stats"].rays == int(g["rays"])
+    g = np.load(os.path.join(GOLD, f"render_{name}_dfs_libm.npz"))
+    r = o.render(s, oracle.ISECT_REF, oracle.RNG_DFS, oracle.MATH_LIBM, 0, frames, rect=CROP)
+    assert np.allclose(r["acc"][y0:y1, x0:x1], g["acc"], rtol=1e-4, atol=1e-5)   # glibc build may differ in the last ulp
+    assert abs(int(r["stats"].rays) - int(g["rays"])) <= 8
+
+
+@pytest.mark.parametrize("name", ["cornell", "default"])
+def test_golden_rays_regression(oracle, name):
+    g = np.load(os.path.join(GOLD, f"rays_{name}.npz"))
+    o = oracle.Scene(MG.scene_data(name))
+    for mode in (oracle.ISECT_BRUTE, oracle.ISECT_REF):
+        h, _ = o.trace_rays(mode, g["origins"], g["dirs"])
+        assert np.array_equal(h["tri"], g["hits"]["tri"]) and np.array_equal(h["t"], g["hits"]["t"])
+    assert (g["hits"]["tri"] >= 0).mean() > 0.5
+
+
+def test_intersector_backends_give_the_same_image(ptlib, oracle):
+    data = MG.scene_data("cornell")
+    o = oracle.Scene(data)
+    nodes, refs = ptlib.Scene(None, data).bvh()
+    o.set_flat_bvh(nodes, refs)
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), 96, 96, 4)
+    imgs = [o.render(s, m, oracle.RNG_DFS, oracle.MATH_LIBM, 0, 2) for m in (oracle.ISECT_REF, oracle.ISECT_FLAT, oracle.ISECT_BRUTE)]
+    for r in imgs[1:]:
+        assert np.array_equal(r["acc"], imgs[0]["acc"]) and r["stats"].rays == imgs[0]["stats"].rays
+    assert imgs[1]["stats"].tri_tests < imgs[2]["stats"].tri_tests      # the BVH actually prunes
+
+
+def test_math_tables_agree(ptlib, oracle):
+    o = oracle.Scene(MG.scene_data("default"))
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.DEFAULT_CAMERA), 64, 64, 5)
+    a = o.render(s, oracle.ISECT_REF, oracle.RNG_DFS, oracle.MATH_LIBM, 0, 2)
+    b = o.render(s, oracle.ISECT_REF, oracle.RNG_DFS, oracle.MATH_DET, 0, 2)
+    rel = np.abs(a["acc"] - b["acc"]) / np.maximum(np.abs(a["acc"]), 1e-2)
+    assert (rel < 1e-3).mean() > 0.995                                   # last-ulp direction changes rarely flip a hit
+    assert np.abs(a["ldr"].astype(int) - b["ldr"].astype(int)).max() <= 255 and (a["ldr"] != b["ldr"]).mean() < 0.01
+
+
+def test_rng_orders_agree_statistically(ptlib, oracle):
+    # node-keyed streams are a different sample set of the same estimator: image means must agree within noise
+    o = oracle.Scene(MG.scene_data("cornell"))
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), 64, 64, 4)
+    a = o.render(s, oracle.ISECT_BRUTE, oracle.RNG_DFS, oracle.MATH_DET, 0, 48)["acc"][..., :3]
+    b = o.render(s, oracle.ISECT_BRUTE, oracle.RNG_NODE, oracle.MATH_DET, 0, 48)["acc"][..., :3]
+    ma, mb = a.mean((0, 1)), b.mean((0, 1))
+    assert np.all(np.abs(ma - mb) / ma < 0.08), (ma, mb)
+    assert ma[0] > ma[1] > ma[2]                                         # warm light (1, .8, .5)
+
+
+def test_accumulate_and_tonemap_semantics(ptlib, oracle):
+    o = oracle.Scene(MG.scene_data("cornell"))
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), 48, 48, 3)
+    r0 = o.render(s, oracle.ISECT_BRUTE, oracle.RNG_DFS, oracle.MATH_LIBM, 0, 1)
+    assert np.array_equal(r0["acc"][..., :3], r0["sample"]) and (r0["acc"][..., 3] == 1).all()   # frame 0: weight 1
+    # frame 0 overwrites whatever was accumulated (CUDATracerProg.cu:878,895)
+    junk = np.full((48, 48, 4), 7.0, np.float32)
+    r0b = o.render(s, oracle.ISECT_BRUTE, oracle.RNG_DFS, oracle.MATH_LIBM, 0, 1, acc=junk)
+    assert np.array_equal(r0b["acc"], r0["acc"])
+    # running mean over 3 frames == mean of the three samples (to rounding)
+    samples = [o.render(s, oracle.ISECT_BRUTE, oracle.RNG_DFS, oracle.MATH_LIBM, f, 1, acc=np.zeros((48, 48, 4), np.float32))["sample"] for f in range(3)]
+    r3 = o.render(s, oracle.ISECT_BRUTE, oracle.RNG_DFS, oracle.MATH_LIBM, 0, 3)
+    assert np.allclose(r3["acc"][..., :3], np.mean(samples, 0), rtol=1e-5, atol=1e-6)
+    # LDR: saturate -> Reinhard -> gamma -> truncation, so bytes never exceed 186 and alpha is 255
+    assert r3["ldr"][..., :3].max() <= 186 and (r3["ldr"][..., 3] == 255).all()
+    c = np.clip(r3["acc"][..., :3].astype(np.float64), 0, 1)
+    expect = np.floor((c / (c + 1)) ** (1 / 2.2) * 255)
+    assert np.abs(r3["ldr"][..., :3].astype(int) - expect).max() <= 1
+    # ray budget: at most 2^maxDepth - 1 rays per sample
+    assert r3["rays"].max() <= 7 and r3["rays"].min() >= 1
+
+
+def test_maxdepth_zero_and_one(ptlib, oracle):
+    o = oracle.Scene(MG.scene_data("cornell"))
+    cam = ptlib.make_camera(**ptlib.CORNELL_CAMERA)
+    r = o.render(ptlib.make_settings(cam, 32, 32, 0), oracle.ISECT_BRUTE, oracle.RNG_DFS, oracle.MATH_LIBM, 0, 1)
+    assert r["stats"].rays == 0 and not r["sample"].any()
+    r = o.render(ptlib.make_settings(cam, 32, 32, 1), oracle.ISECT_BRUTE, oracle.RNG_DFS, oracle.MATH_LIBM, 0, 1)
+    assert r["stats"].rays == 32 * 32            # only emission of directly visible surfaces
+    lit = r["sample"].reshape(-1, 3)
+    assert set(map(tuple, np.unique(lit, axis=0))) <= {(0.0, 0.0, 0.0), (10.0, 8.0, 5.0)}

@@ -1,0 +1,152 @@
+"""Callers' scene construction (product C++ vs the oracle's independent restatement) and the product's BVH builders,
+checked structurally and functionally with the oracle.  CPU only: host-only scenes need no GPU."""
+import numpy as np
+import pytest
+
+from conftest import random_rays, soup_scene
+from test_oracle_kat import ulp_diff
+
+
+@pytest.mark.parametrize("which,ntris,nmesh", [(0, 36, 8), (1, 12506, 5)])
+def test_builtin_scenes_identical_to_oracle_restatement(ptlib, oracle, which, ntris, nmesh):
+    a = ptlib.builtin_scene(which)
+    b = oracle.builtin_meshes(which)
+    assert len(a.meshes) == len(b) == nmesh and a.triangle_count == ntris
+    for (v, i, m), (v2, i2, m2) in zip(a.meshes, b):
+        assert v.tobytes() == v2.tobytes() and i.tobytes() == i2.tobytes() and bytes(m) == bytes(m2)
+    assert bytes(a.sky) == bytes(oracle.builtin_sky(which))
+
+
+def test_sphere_and_cube_counts(ptlib):
+    import ctypes as C
+    for kind, nv, ni in ((0, 4, 6), (1, 24, 36), (2, 3122, 6240 * 3)):
+        icnt = C.c_uint32(0)
+        assert ptlib.lib.mipt_make_mesh(kind, None, None, 0, None, 0, C.byref(icnt)) == nv
+        assert icnt.value == ni
+
+
+def test_cornell_layout(ptlib):
+    # light quad 1e-5 below the ceiling, red wall at z=-2 (viewer's left), camera looks down +x
+    d = ptlib.builtin_scene(0)
+    light = d.meshes[5][0]["position"]
+    assert np.allclose(light[:, 1], 1.99999, atol=1e-6) and np.abs(light[:, [0, 2]]).max() <= 0.5 + 1e-6
+    assert d.meshes[5][2].emissiveStrength == 10.0
+    assert tuple(d.meshes[3][2].color) == (1.0, 0.0, 0.0) and tuple(d.meshes[4][2].color) == (0.0, 1.0, 0.0)
+    allp = np.concatenate([m[0]["position"] for m in d.meshes])
+    assert np.allclose(allp.min(0), -2, atol=1e-5) and np.allclose(allp.max(0), 2, atol=1e-5)
+    assert d.sky.intensity == 0.0
+
+
+def test_camera_matches_oracle(ptlib, oracle):
+    for kw in (ptlib.CORNELL_CAMERA, ptlib.DEFAULT_CAMERA, dict(pos=(1, 2, 3), azimuth=0.7, zenith=1.1, fov=0.9)):
+        a, b = ptlib.make_camera(**kw), oracle.make_camera(**kw)
+        assert bytes(a) == bytes(b)
+    c = ptlib.make_camera(**ptlib.CORNELL_CAMERA)
+    assert abs(c.front[0] - 1) < 1e-6 and abs(c.right[2] - 1) < 1e-6 and abs(c.up[1] - 1) < 1e-6
+
+
+def decode(ref):
+    return bool(ref & 0x80000000), (ref >> 27) & 0xF, ref & 0x07FFFFFF
+
+
+@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("scene", ["cornell", "default", "soup"])
+def test_flat_bvh_valid_and_equal_to_brute_force(ptlib, oracle, builder, scene):
+    data = {"cornell": lambda: ptlib.builtin_scene(0), "default": lambda: ptlib.builtin_scene(1),
+            "soup": lambda: soup_scene(10000, 5)}[scene]()
+    sc = ptlib.Scene(None, data, builder=builder)
+    nodes, refs = sc.bvh()
+    assert len(refs) >= data.triangle_count
+    o = oracle.Scene(data)
+    o.set_flat_bvh(nodes, refs)
+    assert o.check_flat_bvh() == (0, "")
+    # leaf sizes respect the default maximum of 4; children boxes are well formed
+    kids = nodes[:, 12:14].view(np.uint32)
+    leaf = (kids & 0x80000000) != 0
+    assert (((kids >> 27) & 0xF)[leaf] <= 4).all()
+    assert (nodes[:, 0:3] <= nodes[:, 3:6]).all() and (nodes[:, 6:9] <= nodes[:, 9:12]).all()
+    og, dg = random_rays(20000, 21)
+    a, st = o.trace_rays(oracle.ISECT_FLAT, og, dg)
+    b, _ = o.trace_rays(oracle.ISECT_BRUTE, og, dg)
+    diff = np.nonzero((a["tri"] != b["tri"]) | (a["t"] != b["t"]))[0]
+    assert len(diff) <= 40, len(diff)                     # coplanar ties within an ulp / knife-edge box misses only
+    assert (ulp_diff(a["t"][diff], b["t"][diff]) <= 4).sum() >= len(diff) - 3
+    assert st.node_visits > 0 and st.tri_tests > 0
+
+
+def test_sbvh_spatial_splits_duplicate_references(ptlib, oracle):
+    # two huge ground triangles under 2000 small ones: an object split must put the ground in one child and blow
+    # its box up; the spatial split chops the ground instead and duplicates its references
+    rng = np.random.default_rng(2)
+    n = 2002
+    c = rng.uniform(-4, 4, (n - 2, 1, 3)) * (1, 0, 1) + (0, 0.25, 0)
+    small = c + rng.uniform(-0.1, 0.1, (n - 2, 3, 3))
+    ground = np.array([[(-4, 0, -4), (-4, 0, 4), (4, 0, 4)], [(-4, 0, -4), (4, 0, 4), (4, 0, -4)]], np.float64)
+    v = np.zeros(3 * n, ptlib.VERTEX_DTYPE)
+    v["position"] = np.concatenate([ground, small]).astype(np.float32).reshape(-1, 3)
+    v["normal"] = (0, 1, 0)
+    data = ptlib.SceneData([(v, np.arange(3 * n, dtype=np.uint32), ptlib.make_material())], ptlib.SkyLight())
+    nodes, refs = ptlib.Scene(None, data).bvh()
+    assert len(refs) > n
+    o = oracle.Scene(data)
+    o.set_flat_bvh(nodes, refs)
+    assert o.check_flat_bvh() == (0, "")
+    og, dg = random_rays(20000, 4, -4, 4)
+    og[:, 1] = np.abs(og[:, 1]) * 0.2
+    f, sf = o.trace_rays(oracle.ISECT_FLAT, og, dg)
+    b, _ = o.trace_rays(oracle.ISECT_BRUTE, og, dg)
+    assert ((f["tri"] != b["tri"]) | (f["t"] != b["t"])).sum() <= 10
+    # and it pays: fewer triangle tests than the median tree on the same rays
+    n2, r2 = ptlib.Scene(None, data, builder=1).bvh()
+    o.set_flat_bvh(n2, r2)
+    _, sm = o.trace_rays(oracle.ISECT_FLAT, og, dg)
+    assert sf.tri_tests < sm.tri_tests
+
+
+@pytest.mark.parametrize("ntri", [0, 1, 2, 5])
+def test_tiny_scenes(ptlib, oracle, ntri):
+    data = soup_scene(max(ntri, 1), 9)
+    if ntri == 0:
+        data = ptlib.SceneData([], data.sky)
+    for builder in (0, 1):
+        nodes, refs = ptlib.Scene(None, data, builder=builder).bvh()
+        assert len(nodes) >= 1 and len(refs) == ntri
+        o = oracle.Scene(data)
+        o.set_flat_bvh(nodes, refs)
+        assert o.check_flat_bvh()[0] == 0
+        og, dg = random_rays(2000, 1, -5, 5)
+        f, _ = o.trace_rays(oracle.ISECT_FLAT, og, dg)
+        b, _ = o.trace_rays(oracle.ISECT_BRUTE, og, dg)
+        assert np.array_equal(f["tri"], b["tri"]) and np.array_equal(f["t"], b["t"])
+
+
+def test_degenerate_and_duplicate_triangles(ptlib, oracle):
+    v = np.zeros(3 * 40, ptlib.VERTEX_DTYPE)
+    pos = np.zeros((40, 3, 3), np.float32)
+    pos[:20] = [(0, 0, 0), (0, 0, 1), (1, 0, 1)]            # 20 identical triangles
+    pos[20:30] = [(1, 1, 1), (1, 1, 1), (1, 1, 1)]          # zero-area
+    pos[30:] = [(0, 2, 0), (1, 2, 0), (2, 2, 0)]            # collinear
+    v["position"] = pos.reshape(-1, 3)
+    v["normal"] = (0, 1, 0)
+    data = ptlib.SceneData([(v, np.arange(120, dtype=np.uint32), ptlib.make_material())], ptlib.SkyLight())
+    for builder in (0, 1):
+        nodes, refs = ptlib.Scene(None, data, builder=builder).bvh()
+        o = oracle.Scene(data)
+        o.set_flat_bvh(nodes, refs)
+        assert o.check_flat_bvh()[0] == 0
+        h, _ = o.trace_rays(oracle.ISECT_FLAT, np.array([(0.25, 1, 0.5)], np.float32), np.array([(0, -1, 0)], np.float32))
+        assert h["tri"][0] == 0 and h["t"][0] == 1.0        # lowest id wins the 20-way tie
+
+
+def test_grid_mesh_and_synthetic_sky(ptlib):
+    v, i = ptlib.grid_mesh(32, 8.0, 1.0, 1)
+    assert len(v) == 33 * 33 and len(i) == 32 * 32 * 6 and i.max() == len(v) - 1
+    p = v["position"]
+    assert p[:, 0].min() == -8 and p[:, 0].max() == 8 and 0 <= p[:, 1].min() and p[:, 1].max() <= 1
+    # triangles face +y
+    t = p[i.reshape(-1, 3)]
+    assert (np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])[:, 1] > 0).all()
+    sky = ptlib.synthetic_sky(256, 128, 0x5EED)
+    assert sky.shape == (128, 256, 3) and sky.min() >= 0 and sky.max() == 5.0e4
+    assert np.array_equal(sky, ptlib.synthetic_sky(256, 128, 0x5EED))
+    assert sky[:64].mean() > sky[64:].mean()               # bright sky above, dark ground below
