@@ -58,6 +58,10 @@ class Counters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("frames", C.c_uint64), ("kernel_ms", C.c_double), ("launches", C.c_uint64)]
 
 
+class LevelProfile(C.Structure):
+    _fields_ = [("rays", C.c_uint64 * 32), ("ms", C.c_double * 32), ("launches", C.c_uint64 * 32), ("accumulate_ms", C.c_double)]
+
+
 HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("tri", "<i4"), ("mesh", "<i4"), ("front", "<i4")])
 VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("uv", "<f4", 2)])
 
@@ -75,6 +79,7 @@ lib.mipt_synchronize.argtypes = [_vp]
 lib.mipt_set_option.argtypes = [_vp, C.c_char_p, C.c_int64]
 lib.mipt_get_counters.argtypes = [_vp, C.POINTER(Counters)]
 lib.mipt_reset_counters.argtypes = [_vp]
+lib.mipt_get_level_profile.argtypes = [_vp, C.POINTER(LevelProfile)]
 lib.mipt_scene_create.argtypes = [_vp, C.POINTER(SceneDesc), C.POINTER(_vp)]
 lib.mipt_scene_destroy.argtypes = [_vp]
 lib.mipt_scene_destroy.restype = None
@@ -278,6 +283,11 @@ class Tracer:
         c = Counters()
         self._chk(lib.mipt_get_counters(self.h, C.byref(c)), "get_counters")
         return c
+
+    def level_profile(self):
+        p = LevelProfile()
+        self._chk(lib.mipt_get_level_profile(self.h, C.byref(p)), "get_level_profile")
+        return p
 
     def reset_counters(self):
         self._chk(lib.mipt_reset_counters(self.h), "reset_counters")

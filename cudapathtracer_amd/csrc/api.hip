@@ -31,6 +31,7 @@ struct mipt_tracer {
     int64_t rngMode = MIPT_RNG_NODE;
     int64_t countPixelRays = 0;
     int64_t blocksPerCU = 8;
+    int64_t profileLevels = 0;
     // work buffers
     Queue q[2] = {};
     size_t qcap[2] = { 0, 0 };
@@ -41,6 +42,9 @@ struct mipt_tracer {
     // counters
     uint64_t frames = 0, launches = 0; double kernelMs = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    struct LevelEv { hipEvent_t a, b; int level; };   // level -1 = accumulate
+    std::vector<LevelEv> levelPending;
+    double levelMs[32] = {}; uint64_t levelLaunches[32] = {}; double accumulateMs = 0;
 };
 
 struct mipt_scene {
@@ -84,6 +88,14 @@ void resolve_events(mipt_tracer* t) {
         hipEventDestroy(p.first); hipEventDestroy(p.second);
     }
     t->pending.clear();
+    for (auto& p : t->levelPending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            if (p.level >= 0) { t->levelMs[p.level] += ms; t->levelLaunches[p.level]++; } else t->accumulateMs += ms;
+        }
+        hipEventDestroy(p.a); hipEventDestroy(p.b);
+    }
+    t->levelPending.clear();
 }
 
 // per-frame camera constants: RTProgram::GenRay, CUDATracerProg.cu:369-397
@@ -120,10 +132,10 @@ int mipt_create(int device, mipt_tracer** out) {
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) t->numCU = cu;
     if (hipStreamCreateWithFlags(&t->own, hipStreamNonBlocking) != hipSuccess) { delete t; return MIPT_E_HIP; }
     t->stream = t->own;
-    if (hipMalloc((void**)&t->counts, 64 * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&t->stats, 8 * sizeof(unsigned long long)) != hipSuccess) {
+    if (hipMalloc((void**)&t->counts, 64 * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&t->stats, 40 * sizeof(unsigned long long)) != hipSuccess) {
         mipt_destroy(t); return MIPT_E_NOMEM;
     }
-    hipMemsetAsync(t->stats, 0, 8 * sizeof(unsigned long long), t->stream);
+    hipMemsetAsync(t->stats, 0, 40 * sizeof(unsigned long long), t->stream);
     hipStreamSynchronize(t->stream);
     *out = t;
     return MIPT_OK;
@@ -162,6 +174,7 @@ int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
     else if (k == "queue_budget_mb") { if (v < 1) return fail(t, MIPT_E_INVALID, "queue_budget_mb < 1"); t->queueBudgetMB = v; }
     else if (k == "rng_mode") { if (v != MIPT_RNG_NODE && v != MIPT_RNG_DFS) return fail(t, MIPT_E_INVALID, "bad rng_mode"); t->rngMode = v; }
     else if (k == "count_pixel_rays") t->countPixelRays = v ? 1 : 0;
+    else if (k == "profile_levels") t->profileLevels = v ? 1 : 0;
     else if (k == "blocks_per_cu") { if (v < 1 || v > 32) return fail(t, MIPT_E_INVALID, "blocks_per_cu out of range"); t->blocksPerCU = v; }
     else return fail(t, MIPT_E_INVALID, "unknown option " + k);
     return MIPT_OK;
@@ -179,9 +192,21 @@ int mipt_get_counters(mipt_tracer* t, mipt_counters* out) {
 int mipt_reset_counters(mipt_tracer* t) {
     if (!t) return MIPT_E_INVALID;
     int rc = mipt_synchronize(t); if (rc) return rc;
-    HIPCHK(t, hipMemsetAsync(t->stats, 0, 8 * sizeof(unsigned long long), t->stream));
+    HIPCHK(t, hipMemsetAsync(t->stats, 0, 40 * sizeof(unsigned long long), t->stream));
     HIPCHK(t, hipStreamSynchronize(t->stream));
     t->frames = 0; t->launches = 0; t->kernelMs = 0;
+    for (int i = 0; i < 32; i++) { t->levelMs[i] = 0; t->levelLaunches[i] = 0; }
+    t->accumulateMs = 0;
+    return MIPT_OK;
+}
+
+int mipt_get_level_profile(mipt_tracer* t, mipt_level_profile* out) {
+    if (!t || !out) return MIPT_E_INVALID;
+    int rc = mipt_synchronize(t); if (rc) return rc;
+    unsigned long long st[40];
+    HIPCHK(t, hipMemcpy(st, t->stats, sizeof st, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 32; i++) { out->rays[i] = st[1 + i]; out->ms[i] = t->levelMs[i]; out->launches[i] = t->levelLaunches[i]; }
+    out->accumulate_ms = t->accumulateMs;
     return MIPT_OK;
 }
 
@@ -355,18 +380,24 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
                 A.qin = t->q[k & 1]; A.qout = t->q[(k + 1) & 1];
                 A.inCount = t->counts + k; A.outCount = t->counts + k + 1;
                 int blocks = k == 0 ? std::min<int>((int)((np + 255) / 256), persistentBlocks) : persistentBlocks;
+                mipt_tracer::LevelEv le{ nullptr, nullptr, (int)k };
+                if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, t->stream)); }
                 launch_level(A, k == 0, blocks, t->stream);
+                if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, t->stream)); t->levelPending.push_back(le); }
                 t->launches++;
             }
         }
         const float weight = (float)(1.0 / (frame + 1.0));       // CUDATracerProg.cu:878
+        mipt_tracer::LevelEv ae{ nullptr, nullptr, -1 };
+        if (t->profileLevels) { HIPCHK(t, hipEventCreate(&ae.a)); HIPCHK(t, hipEventCreate(&ae.b)); HIPCHK(t, hipEventRecord(ae.a, t->stream)); }
         launch_accumulate(t->sample, acc_dev, ldr_dev, weight, sum_mode, 0, npix, t->stream);
+        if (t->profileLevels) { HIPCHK(t, hipEventRecord(ae.b, t->stream)); t->levelPending.push_back(ae); }
         t->frames++;
     }
     HIPCHK(t, hipEventRecord(ev1, t->stream));
     t->pending.emplace_back(ev0, ev1);
     HIPCHK(t, hipGetLastError());
-    if (t->pending.size() > 256) resolve_events(t);
+    if (t->pending.size() > 256 || t->levelPending.size() > 4096) resolve_events(t);
     return MIPT_OK;
 }
 

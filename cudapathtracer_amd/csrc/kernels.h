@@ -39,7 +39,7 @@ struct LevelArgs {
     uint32_t* outCount;          // rays appended to qout
     float* sample;               // per-pixel radiance of this frame, 4 floats per pixel (rgb + unused)
     uint32_t* pixelRays;         // optional per-pixel ray counter (tests), may be nullptr
-    unsigned long long* stats;   // [0] rays traced
+    unsigned long long* stats;   // [0] rays traced, [1+level] rays traced at that level
     uint32_t level;              // depth of the rays in qin (0 = primary)
     uint32_t pix0, npix;         // pixel tile handled by this pass
 };

@@ -266,7 +266,10 @@ template <bool PRIMARY>
 __global__ void __launch_bounds__(kBlock) k_level(LevelArgs A) {
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
     const uint32_t n = PRIMARY ? A.npix : *A.inCount;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(A.stats, (unsigned long long)n);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) {
+        atomicAdd(A.stats, (unsigned long long)n);
+        atomicAdd(A.stats + 1 + A.level, (unsigned long long)n);
+    }
     const bool spawn = A.level + 1 < A.F.maxDepth;            // children have ttl-1 > 0 (CUDATracerProg.cu:433)
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += stride) {

@@ -69,6 +69,13 @@ typedef struct {
     uint64_t launches;      /* integrator kernel launches */
 } mipt_counters;
 
+/* per recursion level (0 = primary rays): rays traced, HIP-event time of that level's kernel launches, launches.
+ * Filled only while option "profile_levels" is 1. */
+typedef struct {
+    uint64_t rays[32]; double ms[32]; uint64_t launches[32];
+    double accumulate_ms;        /* accumulate + tonemap kernel */
+} mipt_level_profile;
+
 typedef struct { float t, u, v; int32_t tri; int32_t mesh; int32_t front; } mipt_hit;   /* tri = global triangle id, -1 = miss */
 
 /* ---- tracer: PathTracer ctor/dtor (CUDATracer.cpp:8-148, CUDATracerProg.cu:925-935) ---------------------- */
@@ -80,6 +87,7 @@ int  mipt_synchronize(mipt_tracer*);
 int  mipt_set_option(mipt_tracer*, const char* key, int64_t value);   /* "tile_pixels", "rng_mode", "block" ... */
 int  mipt_get_counters(mipt_tracer*, mipt_counters* out);
 int  mipt_reset_counters(mipt_tracer*);
+int  mipt_get_level_profile(mipt_tracer*, mipt_level_profile* out);
 
 /* ---- scene upload: CUDAScene::CUDAScene (CUDATracer.hpp:133-203) ------------------------------------------ */
 int  mipt_scene_create(mipt_tracer*, const mipt_scene_desc*, mipt_scene** out);

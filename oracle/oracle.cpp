@@ -416,7 +416,7 @@ struct orc_scene {
 namespace {
 
 struct Hit { float t, u, v; int tri; bool front; };   // tri = global id
-struct Counters { uint64_t rays = 0, nodes = 0, tris = 0, hits = 0; };
+struct alignas(128) Counters { uint64_t rays = 0, nodes = 0, tris = 0, hits = 0; };   // one cache line per thread
 
 // Moller-Trumbore on (v0, e1, e2) -- CUDATracerProg.cu:232-263.  Accepts iff t>0 && t<tmin (strict), or -- when
 // `id`/`bestId` are given (>= 0) -- on an exact tie t==tmin if the candidate's global triangle id is lower.  The
@@ -452,13 +452,16 @@ inline RayPre ray_pre(v3 o, v3 d) {                             // CUDATracerPro
     r.ood = mk(o.x * r.idir.x, o.y * r.idir.y, o.z * r.idir.z);
     return r;
 }
+// min/max without libm calls (gcc cannot inline fminf/fmaxf without -ffinite-math-only); operands are never NaN here
+inline float fmin_(float a, float b) { return a < b ? a : b; }
+inline float fmax_(float a, float b) { return a > b ? a : b; }
 // slab test, CUDATracerProg.cu:651-658 with spanBegin/EndKepler (:86-87): tnear = max(0,...), tfar = min(hitT,...)
 inline bool slab(const RayPre& r, const float* mn, const float* mx, float hitT, float* tnear) {
     float lox = ffma(mn[0], r.idir.x, -r.ood.x), hix = ffma(mx[0], r.idir.x, -r.ood.x);
     float loy = ffma(mn[1], r.idir.y, -r.ood.y), hiy = ffma(mx[1], r.idir.y, -r.ood.y);
     float loz = ffma(mn[2], r.idir.z, -r.ood.z), hiz = ffma(mx[2], r.idir.z, -r.ood.z);
-    float tmin = fmaxf(fmaxf(fminf(lox, hix), fminf(loy, hiy)), fmaxf(fminf(loz, hiz), 0.0f));
-    float tmax = fminf(fminf(fmaxf(lox, hix), fmaxf(loy, hiy)), fminf(fmaxf(loz, hiz), hitT));
+    float tmin = fmax_(fmax_(fmin_(lox, hix), fmin_(loy, hiy)), fmax_(fmin_(loz, hiz), 0.0f));
+    float tmax = fmin_(fmin_(fmax_(lox, hix), fmax_(loy, hiy)), fmin_(fmax_(loz, hiz), hitT));
     *tnear = tmin;
     return tmin <= tmax;
 }
@@ -853,9 +856,12 @@ int orc_render(const orc_scene* s, const orc_settings* st, int isect_mode, int r
         orc_settings cur = *st; cur.frameID = f;
         CamPre cp = cam_pre(cur);
         float weight = (float)(1.0 / (f + 1.0));                  // CUDATracerProg.cu:878
-        parallel_rows(y0, y1, nthreads, [&](uint32_t j, int t) {
+        // work items = 64-pixel spans of a row, so that even a one-row rectangle keeps every thread busy
+        const uint32_t span = 64, spansPerRow = (x1 - x0 + span - 1) / span;
+        parallel_rows(0, (y1 - y0) * spansPerRow, nthreads, [&](uint32_t item, int t) {
+            const uint32_t j = y0 + item / spansPerRow, xs = x0 + (item % spansPerRow) * span, xe = std::min(x1, xs + span);
             Ctx k; k.s = s; k.isect = isect_mode; k.rng_mode = rng_mode; k.M = &M; k.c = &cs[t]; k.s0 = 0; k.pixel_rays = 0;
-            for (uint32_t i = x0; i < x1; i++) {
+            for (uint32_t i = xs; i < xe; i++) {
                 v3 c = GenRay(k, cur, cp, (int)i, (int)j);
                 size_t addr = ((size_t)j * W + i) * 4;
                 if (sample) { size_t a3 = ((size_t)j * W + i) * 3; sample[a3] = c.x; sample[a3 + 1] = c.y; sample[a3 + 2] = c.z; }
