@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--depth", type=int, default=0, help="0 = 8 for cornell, 12 for default (BASELINE.json)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU oracle budget (0 disables cpu_baseline)")
     p.add_argument("--tile-pixels", type=int, default=0)
+    p.add_argument("--integrator", type=int, default=0, help="0 persistent wave stacks (default), 1 level-synchronous queues")
     p.add_argument("--traffic-gb", type=float, default=None, help="HBM bytes per k_level<false> launch from a PMC run (GB)")
     return p.parse_args()
 
@@ -76,7 +77,8 @@ def oracle_sample(pt, data, bvh, settings, seconds, threads):
     return dict(rows=len(rows), rays=full["rays"], sec=full["sec"], mrays=full["rays"] / full["sec"] / 1e6,
                 n_node=(full["nodes"] - prim["nodes"]) / sec_rays, n_tri=(full["tris"] - prim["tris"]) / sec_rays,
                 miss_frac=1.0 - (full["hits"] - prim["hits"]) / sec_rays,
-                n_node_all=full["nodes"] / max(full["rays"], 1), n_tri_all=full["tris"] / max(full["rays"], 1))
+                n_node_all=full["nodes"] / max(full["rays"], 1), n_tri_all=full["tris"] / max(full["rays"], 1),
+                miss_all=1.0 - full["hits"] / max(full["rays"], 1))
 
 
 def main():
@@ -109,6 +111,7 @@ def main():
     t = pt.Tracer(local)
     if a.tile_pixels:
         t.set_option("tile_pixels", a.tile_pixels)
+    t.set_option("integrator", a.integrator)
     sc = pt.Scene(t, data)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     ldr = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
@@ -157,15 +160,22 @@ def main():
     total_rays, dt = float(rays.item()), float(tmax.item())
 
     if rank == 0:
-        sec_rays = sum(prof.rays[k] for k in range(1, 32))
-        sec_ms = sum(prof.ms[k] for k in range(1, 32))
-        sec_launches = sum(prof.launches[k] for k in range(1, 32))
+        if a.integrator == 0:    # one k_wavestack launch per frame traces every ray of the frame
+            kernel_name = "mipt::k_wavestack<%s>" % ("true" if data.triangle_count * 3 + 4 * 64 <= 1024 else "false")
+            sec_rays, sec_ms, sec_launches = float(cnt.rays), prof.ms[0], prof.launches[0]
+        else:                    # k_level<false,*> launches carry the non-primary levels
+            kernel_name = "mipt::k_level<false,*>"
+            sec_rays = sum(prof.rays[k] for k in range(1, 32))
+            sec_ms = sum(prof.ms[k] for k in range(1, 32))
+            sec_launches = sum(prof.launches[k] for k in range(1, 32))
         cpu = None
         n_node = n_tri = miss = None
         if a.cpu_seconds > 0:
             threads = min(os.cpu_count() or 1, 16)
             cpu = oracle_sample(pt, data, sc.bvh(), settings, a.cpu_seconds if world == 1 else min(a.cpu_seconds, 3.0), threads)
             n_node, n_tri, miss = cpu["n_node"], cpu["n_tri"], cpu["miss_frac"]
+            if a.integrator == 0:
+                n_node, n_tri, miss = cpu["n_node_all"], cpu["n_tri_all"], cpu["miss_all"]
         roof = None
         if n_node is not None and sec_ms > 0:
             # B_ray = 64*N_node + 48*N_tri + 64 (+12 per env-map miss); units per launch = rays of that launch
@@ -173,7 +183,7 @@ def main():
             achieved = sec_rays * b_ray / (sec_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": a.traffic_gb,
-                    "kernel": "mipt::k_level<false>", "bytes_per_ray": round(b_ray, 1), "n_node_per_ray": round(n_node, 3),
+                    "kernel": kernel_name, "bytes_per_ray": round(b_ray, 1), "n_node_per_ray": round(n_node, 3),
                     "n_tri_per_ray": round(n_tri, 3), "rays_per_launch": round(sec_rays / max(sec_launches, 1), 1),
                     "avg_launch_ms": round(sec_ms / max(sec_launches, 1), 4), "launches": int(sec_launches),
                     "note": "working set (BVH+triangles) is cache/LDS resident for this workload: algorithmic bytes are served on-chip, so frac is not an HBM utilisation"}
@@ -182,12 +192,12 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.workload}_{W}x{H}_{depth}bounce_1spp_per_gpu_step", "width": W, "height": H, "max_depth": depth,
-                       "triangles": data.triangle_count, "bvh": "sbvh", "rng": "node", "parallelism": f"sample-striding x{world}",
+                       "triangles": data.triangle_count, "bvh": "sbvh", "rng": "node", "integrator": "wave-stacks" if a.integrator == 0 else "level-queues", "parallelism": f"sample-striding x{world}",
                        "env_map": None if data.env is None else "synthetic 2048x1024"},
             "spp_per_s": round(a.steps * world / dt, 3), "rays_per_step_per_gpu": round(total_rays / a.steps / world, 1),
             "shadow_rays": 0, "kernel_ms_per_step": round(cnt.kernel_ms / a.steps, 3),
-            "level_ms": [round(prof.ms[k] / a.steps, 3) for k in range(depth)],
-            "level_mrays": [round(prof.rays[k] / a.steps / 1e6, 2) for k in range(depth)],
+            "level_ms": [round(prof.ms[k] / a.steps, 3) for k in range(depth)] if a.integrator else None,
+            "level_mrays": [round(prof.rays[k] / a.steps / 1e6, 2) for k in range(depth)] if a.integrator else None,
             "accumulate_ms": round(prof.accumulate_ms / a.steps, 3),
             "roofline": roof,
         }

@@ -32,7 +32,9 @@ struct mipt_tracer {
     int64_t countPixelRays = 0;
     int64_t blocksPerCU = 8;
     int64_t profileLevels = 0;
+    int64_t integrator = 0;          // 0 persistent wave stacks, 1 level-synchronous queues
     // work buffers
+    Queue wstack = {}; size_t wstackEntries = 0;
     Queue q[2] = {};
     size_t qcap[2] = { 0, 0 };
     uint32_t* counts = nullptr;               // per-level queue counters
@@ -146,7 +148,7 @@ void mipt_destroy(mipt_tracer* t) {
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
     resolve_events(t);
-    free_queue(t->q[0]); free_queue(t->q[1]);
+    free_queue(t->q[0]); free_queue(t->q[1]); free_queue(t->wstack);
     if (t->counts) hipFree(t->counts);
     if (t->stats) hipFree(t->stats);
     if (t->sample) hipFree(t->sample);
@@ -175,6 +177,7 @@ int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
     else if (k == "rng_mode") { if (v != MIPT_RNG_NODE && v != MIPT_RNG_DFS) return fail(t, MIPT_E_INVALID, "bad rng_mode"); t->rngMode = v; }
     else if (k == "count_pixel_rays") t->countPixelRays = v ? 1 : 0;
     else if (k == "profile_levels") t->profileLevels = v ? 1 : 0;
+    else if (k == "integrator") { if (v != 0 && v != 1) return fail(t, MIPT_E_INVALID, "integrator must be 0 (wave stacks) or 1 (level queues)"); t->integrator = v; }
     else if (k == "blocks_per_cu") { if (v < 1 || v > 32) return fail(t, MIPT_E_INVALID, "blocks_per_cu out of range"); t->blocksPerCU = v; }
     else return fail(t, MIPT_E_INVALID, "unknown option " + k);
     return MIPT_OK;
@@ -343,9 +346,22 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
         HIPCHK(t, hipMalloc((void**)&t->pixelRays, (size_t)npix * 4));
         t->pixelRaysCap = npix;
     }
-    // tile size: rays at level k <= tile * 2^k; the two ping-pong queues hold the largest odd / even level
+    const int persistentBlocks = t->numCU * (int)t->blocksPerCU;
     uint32_t tile = npix;
-    if (D >= 2) {
+    uint32_t wcap = 0;
+    if (t->integrator == 0) {
+        // persistent wave stacks: 128 entries per recursion level per wave (see k_wavestack), independent of the viewport
+        wcap = 128u * std::max<uint32_t>(D, 1u) + 64u;
+        const size_t need = (size_t)persistentBlocks * 4 * wcap;
+        if (t->wstackEntries < need) {
+            free_queue(t->wstack); t->wstackEntries = 0;
+            HIPCHK(t, hipMalloc((void**)&t->wstack.a, need * sizeof(float4)));
+            HIPCHK(t, hipMalloc((void**)&t->wstack.b, need * sizeof(float4)));
+            HIPCHK(t, hipMalloc((void**)&t->wstack.c, need * sizeof(float4)));
+            t->wstackEntries = need;
+        }
+    } else if (D >= 2) {
+    // tile size: rays at level k <= tile * 2^k; the two ping-pong queues hold the largest odd / even level
         uint64_t maxEntries = (uint64_t)t->queueBudgetMB * 1024 * 1024 / 48;
         uint64_t perPixel = (1ull << (D - 1)) + (D >= 3 ? (1ull << (D - 2)) : 0);
         uint64_t fit = maxEntries / perPixel;
@@ -359,7 +375,6 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
         int rc = ensure_queue(t, 1, (size_t)tile << oddMax); if (rc) return rc;
         if (evenMax >= 2) { rc = ensure_queue(t, 0, (size_t)tile << evenMax); if (rc) return rc; }
     }
-    const int persistentBlocks = t->numCU * (int)t->blocksPerCU;
 
     hipEvent_t ev0, ev1;
     HIPCHK(t, hipEventCreate(&ev0)); HIPCHK(t, hipEventCreate(&ev1));
@@ -371,6 +386,17 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
         LevelArgs A;
         A.S = sc->dev; A.F = make_frame(*st, frame);
         A.sample = t->sample; A.pixelRays = t->countPixelRays ? t->pixelRays : nullptr; A.stats = t->stats;
+        if (t->integrator == 0 && D >= 1) {
+            HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), t->stream));
+            StackArgs SA;
+            SA.S = sc->dev; SA.F = A.F; SA.stack = t->wstack; SA.cap = wcap; SA.pixCounter = t->counts;
+            SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npix;
+            mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
+            if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, t->stream)); }
+            launch_wavestack(SA, std::min<int>((int)((npix + 255) / 256), persistentBlocks), t->stream);
+            if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, t->stream)); t->levelPending.push_back(le); }
+            t->launches++;
+        } else
         for (uint32_t p0 = 0; p0 < npix; p0 += tile) {
             const uint32_t np = std::min(tile, npix - p0);
             HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), t->stream));

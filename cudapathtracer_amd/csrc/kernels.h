@@ -44,6 +44,17 @@ struct LevelArgs {
     uint32_t pix0, npix;         // pixel tile handled by this pass
 };
 
+// Persistent wave-private work stacks (the default integrator): every wave owns `cap` ray slots of the three SoA
+// arrays and runs its rays' whole recursion trees out of that LIFO, refilling idle lanes with fresh primary rays.
+struct StackArgs {
+    SceneDev S; FrameDev F;
+    Queue stack;                 // waves * cap entries, wave w owns [w*cap, (w+1)*cap)
+    uint32_t cap;                // >= 128 * maxDepth
+    uint32_t* pixCounter;        // next unclaimed pixel of the frame (reset to 0 before the launch)
+    float* sample; uint32_t* pixelRays; unsigned long long* stats;
+    uint32_t pix0, npix;
+};
+
 struct DfsArgs {
     SceneDev S; FrameDev F;
     float* sample; uint32_t* pixelRays; unsigned long long* stats;
@@ -51,6 +62,7 @@ struct DfsArgs {
 };
 
 void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s);
+void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s);
 void launch_dfs(const DfsArgs& a, int blocks, hipStream_t s);
 void launch_accumulate(const float* sample, float* acc, unsigned char* ldr, float weight, int sumMode,
                        uint32_t pix0, uint32_t npix, hipStream_t s);

@@ -85,7 +85,11 @@ struct Stack {
 
 // Closest hit (TraceRay, CUDATracerProg.cu:543-794) on the flat scene BVH.  Near child first, far child pushed;
 // leaves are tested when they become current; hitT shrinks as hits are found and culls later box tests.
-MIPT_DEV HitRec traverse(const SceneDev& S, v3 o, v3 d, uint32_t* ldsStack) {
+// With LDS_SCENE the whole node + reference stream has been copied into LDS by the block (scenes of a few KB, e.g. the
+// Cornell box): `nodes`/`refs` then point into LDS and every dependent fetch of the walk costs an LDS round trip
+// instead of an L1/L2 one.
+template <typename NodePtr, typename RefPtr>
+MIPT_DEV HitRec traverse(NodePtr nodes, RefPtr refs, v3 o, v3 d, uint32_t* ldsStack) {
     RayPre r = ray_pre(o, d);
     HitRec h; h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
     Stack st; st.lds = ldsStack; st.sp = 0;
@@ -93,7 +97,7 @@ MIPT_DEV HitRec traverse(const SceneDev& S, v3 o, v3 d, uint32_t* ldsStack) {
     uint32_t cur = 0;
     while (true) {
         while (!(cur & kLeaf)) {
-            const float4* N = S.nodes + (size_t)cur * 4;
+            auto N = nodes + (size_t)cur * 4;
             float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
             float t0, t1;
             bool h0 = slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, h.t, t0);
@@ -114,7 +118,7 @@ MIPT_DEV HitRec traverse(const SceneDev& S, v3 o, v3 d, uint32_t* ldsStack) {
         if (cur == kTerm) break;
         uint32_t cnt = (cur >> 27) & 0xFu, first = cur & 0x07FFFFFFu;
         for (uint32_t i = first; i < first + cnt; i++) {
-            const float4* T = S.refs + (size_t)i * 3;
+            auto T = refs + (size_t)i * 3;
             float4 a = T[0], b = T[1], c = T[2];
             float tt, uu, vv; bool ff;
             int id = (int)__float_as_uint(a.w);
@@ -262,9 +266,18 @@ MIPT_DEV void add_sample(float* sample, uint32_t pix, v3 c) {
 // =================================================================================================================
 // Wavefront level kernel.  Persistent grid-stride over the input queue; every lane handles one ray per iteration.
 // =================================================================================================================
-template <bool PRIMARY>
+constexpr uint32_t kLdsSceneVec = 1024;    // float4 slots (16 KiB) for an LDS-resident scene
+
+template <bool PRIMARY, bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock) k_level(LevelArgs A) {
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneVec : 1];
+    if (LDS_SCENE) {
+        const uint32_t nn = A.S.nNodes * 4, nr = A.S.nRefs * 3;
+        for (uint32_t i = threadIdx.x; i < nn; i += kBlock) ldsScene[i] = A.S.nodes[i];
+        for (uint32_t i = threadIdx.x; i < nr; i += kBlock) ldsScene[nn + i] = A.S.refs[i];
+        __syncthreads();
+    }
     const uint32_t n = PRIMARY ? A.npix : *A.inCount;
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) {
         atomicAdd(A.stats, (unsigned long long)n);
@@ -289,7 +302,8 @@ __global__ void __launch_bounds__(kBlock) k_level(LevelArgs A) {
                 pix = __float_as_uint(qc.y); node = __float_as_uint(qc.z); s0 = __float_as_uint(qc.w);
             }
             if (A.pixelRays) atomicAdd(A.pixelRays + pix, 1u);
-            HitRec h = traverse(A.S, o, d, ldsStack + threadIdx.x);
+            HitRec h = LDS_SCENE ? traverse((const float4*)ldsScene, (const float4*)ldsScene + A.S.nNodes * 4, o, d, ldsStack + threadIdx.x)
+                                 : traverse(A.S.nodes, A.S.refs, o, d, ldsStack + threadIdx.x);
             if (h.ref < 0) {
                 add_sample(A.sample, pix, beta * on_miss(A.S, d));
             } else {
@@ -334,8 +348,118 @@ __global__ void __launch_bounds__(kBlock) k_level(LevelArgs A) {
 }
 
 void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s) {
-    if (primary) hipLaunchKernelGGL(k_level<true>, dim3(blocks), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL(k_level<false>, dim3(blocks), dim3(kBlock), 0, s, a);
+    const bool lds = a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec;
+    if (primary) { if (lds) hipLaunchKernelGGL((k_level<true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+                   else hipLaunchKernelGGL((k_level<true, false>), dim3(blocks), dim3(kBlock), 0, s, a); }
+    else { if (lds) hipLaunchKernelGGL((k_level<false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+           else hipLaunchKernelGGL((k_level<false, false>), dim3(blocks), dim3(kBlock), 0, s, a); }
+}
+
+// =================================================================================================================
+// Persistent wave-private work stacks.
+//
+// The level-synchronous kernel above pays one returning atomic on ONE counter per wave-batch to append to the next
+// level's queue; on MI355X a single word sustains only ~90 such atomics per microsecond, which bounded every
+// non-final level (measured: profiles/r1).  Here nothing is shared between waves: a wave keeps its pending rays in
+// its own LIFO region of HBM (hot top in L2), pops 64 per iteration, and pushes the children back with the same
+// ballot/prefix compaction -- the "allocation" is a wave-uniform stack pointer.  Idle lanes are refilled with new
+// primary rays claimed 64 at a time from a frame-wide pixel counter (one atomic per refill), so lanes stay full until
+// the frame runs dry and one launch renders the whole frame.
+//
+// Stack bound: entries are kept sorted by recursion level (primaries enter in the lowest lanes, children are pushed
+// in lane order), so when level-L rays are pushed every older level->=L ray has just been popped; each level holds at
+// most 128 entries, the stack at most 128 * (maxDepth - 1).
+// =================================================================================================================
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(kBlock) k_wavestack(StackArgs A) {
+    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneVec : 1];
+    if (LDS_SCENE) {
+        const uint32_t nn = A.S.nNodes * 4, nr = A.S.nRefs * 3;
+        for (uint32_t i = threadIdx.x; i < nn; i += kBlock) ldsScene[i] = A.S.nodes[i];
+        for (uint32_t i = threadIdx.x; i < nr; i += kBlock) ldsScene[nn + i] = A.S.refs[i];
+        __syncthreads();
+    }
+    const uint32_t lane = __lane_id();
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const size_t wbase = (size_t)wave * A.cap;
+    float4* __restrict__ qa = A.stack.a + wbase;
+    float4* __restrict__ qb = A.stack.b + wbase;
+    float4* __restrict__ qc = A.stack.c + wbase;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t sp = 0;                 // wave-uniform
+    bool more = true;                // wave-uniform: the frame may still have unclaimed pixels
+    uint32_t traced = 0;             // per-lane ray count
+    while (true) {
+        const uint32_t take = sp < 64u ? sp : 64u;
+        uint32_t got = 0, pbase = 0;
+        if (more && take < 64u) {
+            const uint32_t want = 64u - take;
+            if (lane == 0) pbase = atomicAdd(A.pixCounter, want);
+            pbase = __builtin_amdgcn_readfirstlane(pbase);
+            got = pbase < A.npix ? (A.npix - pbase < want ? A.npix - pbase : want) : 0u;
+            if (got < want) more = false;
+        }
+        if (take + got == 0) break;
+        sp -= take;
+        // lanes [0, got) start new primary rays, lanes [got, got + take) continue the rays on top of the stack
+        const bool active = lane < got + take;
+        v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), beta = mk3(1.f, 1.f, 1.f);
+        uint32_t pix = 0, node = 1, s0 = 0;
+        bool has = false;
+        Bounce b;
+        if (active) {
+            if (lane < got) {
+                pix = A.pix0 + pbase + lane;
+                gen_primary(A.F, pix, o, d, s0);
+            } else {
+                const uint32_t e = sp + (lane - got);
+                float4 ra = qa[e], rb = qb[e], rc = qc[e];
+                o = xyz(ra); d = mk3(ra.w, rb.x, rb.y); beta = mk3(rb.z, rb.w, rc.x);
+                pix = __float_as_uint(rc.y); node = __float_as_uint(rc.z); s0 = __float_as_uint(rc.w);
+            }
+            traced++;
+            if (A.pixelRays) atomicAdd(A.pixelRays + pix, 1u);
+            HitRec h = LDS_SCENE ? traverse((const float4*)ldsScene, (const float4*)ldsScene + A.S.nNodes * 4, o, d, ldsStack + threadIdx.x)
+                                 : traverse(A.S.nodes, A.S.refs, o, d, ldsStack + threadIdx.x);
+            if (h.ref < 0) {
+                add_sample(A.sample, pix, beta * on_miss(A.S, d));
+            } else {
+                Surface sf = surface_at(A.S, o, d, h);
+                Material mat = load_material(A.S, sf.mesh);
+                add_sample(A.sample, pix, beta * (mat.emissive * mat.emissiveStrength));
+                const uint32_t level = 31u - (uint32_t)__clz((int)node);       // root = 1 -> level 0
+                if (level + 1 < A.F.maxDepth) {                                  // children have ttl-1 > 0 (CUDATracerProg.cu:433)
+                    Lcg rng; rng.state = node_seed(s0, node);
+                    b = shade_hit(mat, sf, d, h.front, rng);
+                    b.f1 = beta * b.f1; b.f2 = beta * b.f2;
+                    has = true;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(has);
+        if (m) {
+            const uint32_t w = sp + 2u * (uint32_t)__popcll(m & below);
+            if (has) {
+                qa[w] = make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x);
+                qb[w] = make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y);
+                qc[w] = make_float4(b.f1.z, __uint_as_float(pix), __uint_as_float(node * 2u), __uint_as_float(s0));
+                qa[w + 1] = make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x);
+                qb[w + 1] = make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y);
+                qc[w + 1] = make_float4(b.f2.z, __uint_as_float(pix), __uint_as_float(node * 2u + 1u), __uint_as_float(s0));
+            }
+            sp += 2u * (uint32_t)__popcll(m);
+        }
+    }
+    // one counter update per wave
+    for (int sh = 32; sh > 0; sh >>= 1) traced += __shfl_down(traced, sh);
+    if (lane == 0 && traced) atomicAdd(A.stats, (unsigned long long)traced);
+}
+
+void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
+    const bool lds = a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec;
+    if (lds) hipLaunchKernelGGL((k_wavestack<true>), dim3(blocks), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((k_wavestack<false>), dim3(blocks), dim3(kBlock), 0, s, a);
 }
 
 // =================================================================================================================
@@ -385,7 +509,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(SceneDev S, const float* 
     if (i >= n) return;
     v3 ro = mk3(o[(size_t)i * 3], o[(size_t)i * 3 + 1], o[(size_t)i * 3 + 2]);
     v3 rd = mk3(d[(size_t)i * 3], d[(size_t)i * 3 + 1], d[(size_t)i * 3 + 2]);
-    HitRec h = traverse(S, ro, rd, ldsStack + threadIdx.x);
+    HitRec h = traverse(S.nodes, S.refs, ro, rd, ldsStack + threadIdx.x);
     HitOut r; r.t = h.t; r.u = h.u; r.v = h.v; r.front = h.front ? 1 : 0;
     if (h.ref >= 0) {
         r.tri = h.tri;
