@@ -10,7 +10,7 @@ scene is replicated, rank r renders frame indices r, r+N, ... into a private sum
 GPU per step) and ONE RCCL reduce of the accumulation buffers closes the timed region.
 
 Prints ONE JSON line on rank 0: whole-job Mrays/s (closest-hit extension rays; the reference traces no shadow rays)
-plus spp/s, a roofline object for the dominant kernel (k_level<false>, the wavefront extend+shade kernel) and, at
+plus spp/s, a roofline object for the dominant kernel (k_wavestack, the persistent extend+shade kernel) and, at
 N = 1, the CPU oracle timed on this host as a reported baseline.
 """
 import argparse
@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU oracle budget (0 disables cpu_baseline)")
     p.add_argument("--tile-pixels", type=int, default=0)
     p.add_argument("--integrator", type=int, default=0, help="0 persistent wave stacks (default), 1 level-synchronous queues")
-    p.add_argument("--traffic-gb", type=float, default=None, help="HBM bytes per k_level<false> launch from a PMC run (GB)")
+    p.add_argument("--traffic-gb", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC run (GB)")
     return p.parse_args()
 
 
@@ -161,7 +161,8 @@ def main():
 
     if rank == 0:
         if a.integrator == 0:    # one k_wavestack launch per frame traces every ray of the frame
-            kernel_name = "mipt::k_wavestack<%s>" % ("true" if data.triangle_count * 3 + 4 * 64 <= 1024 else "false")
+            nn, nr = (len(x) for x in sc.bvh())
+            kernel_name = "mipt::k_wavestack<%s>" % ("true" if nn * 4 + nr * 3 <= 1024 else "false")   # LDS-resident scene?
             sec_rays, sec_ms, sec_launches = float(cnt.rays), prof.ms[0], prof.launches[0]
         else:                    # k_level<false,*> launches carry the non-primary levels
             kernel_name = "mipt::k_level<false,*>"

@@ -120,6 +120,9 @@ lib.mipt_make_synthetic_sky.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _vp]
 lib.mipt_make_synthetic_sky.restype = None
 lib.mipt_make_grid_mesh.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_uint32, _vp, _vp]
 lib.mipt_make_grid_mesh.restype = C.c_uint32
+lib.mipt_rgbe_decode.argtypes = [_vp, C.c_size_t, _vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+lib.mipt_rgbe_encode.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp, C.c_size_t]
+lib.mipt_rgbe_encode.restype = C.c_size_t
 lib.mipt_test_math.argtypes = [_vp, C.c_int, _vp, _vp, C.c_uint32, _vp]
 
 
@@ -184,6 +187,26 @@ def synthetic_sky(w=2048, h=1024, seed=0x5EED):
     img = np.zeros((h, w, 3), np.float32)
     lib.mipt_make_synthetic_sky(w, h, seed, _ptr(img))
     return img
+
+
+def rgbe_decode(data):
+    """bytes of a Radiance .hdr file -> float32 [H, W, 3] (top row first); raises MiptError on malformed input."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    if lib.mipt_rgbe_decode(_ptr(buf), len(buf), None, C.byref(w), C.byref(h)) != 0:
+        raise MiptError("malformed RGBE data")
+    img = np.zeros((h.value, w.value, 3), np.float32)
+    lib.mipt_rgbe_decode(_ptr(buf), len(buf), _ptr(img), C.byref(w), C.byref(h))
+    return img
+
+
+def rgbe_encode(img):
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape[:2]
+    n = lib.mipt_rgbe_encode(_ptr(img), w, h, None, 0)
+    out = np.zeros(n, np.uint8)
+    lib.mipt_rgbe_encode(_ptr(img), w, h, _ptr(out), n)
+    return out.tobytes()
 
 
 def grid_mesh(n, extent=8.0, height=1.0, seed=1):

@@ -1,0 +1,90 @@
+// RendererWindow.hpp -- headless work-alike of the reference's window driver (Common/RendererWindow.hpp:9-185,
+// Common/GLFWWindow.cpp:128-147): same members and call sequence (resize -> loop { Trace; bitmap->cpu_data();
+// frameID++ }), no GLFW/OpenGL.  DrawBitmap keeps the last frame and can write it as a PPM instead of blitting it.
+#pragma once
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "CUDATracer.hpp"
+#include "Scenes.hpp"
+
+class RendererWindow {
+protected:
+    CUDATracer::Math::vec2i bitmapSize;
+    std::shared_ptr<CUDATracer::CUDABuffer> bitmap;
+    std::shared_ptr<CUDATracer::CUDABuffer> accBuffer;
+    std::shared_ptr<CUDATracer::TypedBuffer<CUDATracer::PathTraceSettings>> renderSettings;
+    CUDATracer::CUDAScene renderScene;
+    CUDATracer::PathTracer* renderer;
+    std::vector<std::uint8_t> lastFrame;
+    unsigned width, height;
+
+    void UpdateCam(CUDATracer::Camera& cam) { CUDATracer::Scenes::UpdateCam(camParam, cam); }
+
+public:
+    using CameraParams = CUDATracer::Scenes::CameraParams;
+    CameraParams camParam;
+
+    RendererWindow(const CUDATracer::Scene& scene, const std::string& title = "CUDAPathTracer", unsigned width_ = 800, unsigned height_ = 480)
+        : renderScene(scene), camParam{}, width(width_), height(height_) {
+        (void)title;
+        renderer = CUDATracer::MakeCUDATracerProg();
+        renderSettings = std::make_shared<CUDATracer::TypedBuffer<CUDATracer::PathTraceSettings>>();
+        camParam = CUDATracer::Scenes::DefaultCamera();
+        auto& settings = renderSettings->GetMutable<0>();
+        UpdateCam(settings.cam);
+        settings.viewportHeight = height; settings.viewportWidth = width;
+        settings.frameID = 0; settings.maxDepth = 8;
+    }
+    virtual ~RendererWindow() { renderSettings = nullptr; bitmap = nullptr; accBuffer = nullptr; delete renderer; }
+
+    void ResetFrameID() { renderSettings->GetMutable<0>().frameID = 0; }
+
+    virtual void resize(const CUDATracer::Math::vec2i& newSize) {
+        bitmapSize = newSize;
+        size_t n = (size_t)newSize.x * newSize.y * 4;
+        accBuffer = std::make_shared<CUDATracer::CUDABuffer>(n * sizeof(float));
+        bitmap = std::make_shared<CUDATracer::CUDABuffer>(n * sizeof(char));
+        auto& settings = renderSettings->GetMutable<0>();
+        settings.viewportHeight = newSize.y; settings.viewportWidth = newSize.x;
+        ResetFrameID();
+    }
+    virtual void Update() { UpdateCam(renderSettings->GetMutable<0>().cam); }
+
+    virtual void render() {
+        renderer->Trace(renderScene, *renderSettings, (float*)accBuffer->mutable_gpu_data(), (char*)bitmap->mutable_gpu_data());
+        auto tbuffer = (const std::uint8_t*)bitmap->cpu_data();       // blocking readback, observes the frame
+        renderSettings->GetMutable<0>().frameID++;                    // the CALLER advances the sample index
+        DrawBitmap(bitmapSize.x, bitmapSize.y, tbuffer);
+    }
+    virtual void DrawBitmap(int w, int h, const std::uint8_t* rgba) { lastFrame.assign(rgba, rgba + (size_t)w * h * 4); }
+
+    // GLFWWindow::run with a frame budget instead of a close button
+    void run(unsigned frames) {
+        resize({ (int)width, (int)height });
+        for (unsigned f = 0; f < frames; f++) { Update(); render(); }
+    }
+    unsigned frameID() { return renderSettings->Get<0>().frameID; }
+    const float* accumulation() { return (const float*)accBuffer->cpu_data(); }
+    const std::vector<std::uint8_t>& frame() const { return lastFrame; }
+
+    bool WritePPM(const std::string& path) const {      // row 0 of the buffers is the BOTTOM of the image
+        FILE* f = std::fopen(path.c_str(), "wb");
+        if (!f) return false;
+        std::fprintf(f, "P6 %d %d 255\n", bitmapSize.x, bitmapSize.y);
+        for (int y = bitmapSize.y - 1; y >= 0; y--) for (int x = 0; x < bitmapSize.x; x++) std::fwrite(&lastFrame[((size_t)y * bitmapSize.x + x) * 4], 1, 3, f);
+        std::fclose(f);
+        return true;
+    }
+    bool WritePFM(const std::string& path) {             // PFM is bottom-up like the buffers
+        const float* a = accumulation();
+        FILE* f = std::fopen(path.c_str(), "wb");
+        if (!f) return false;
+        std::fprintf(f, "PF\n%d %d\n-1.0\n", bitmapSize.x, bitmapSize.y);
+        for (size_t p = 0; p < (size_t)bitmapSize.x * bitmapSize.y; p++) std::fwrite(a + p * 4, sizeof(float), 3, f);
+        std::fclose(f);
+        return true;
+    }
+};

@@ -2,6 +2,7 @@
 // header-only CUDATracer host API in ../cpp so that Python tests and C++ callers build byte-identical inputs.
 #include "../../include/mipt.h"
 #include "../cpp/Scenes.hpp"
+#include "../cpp/Rgbe.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -61,6 +62,21 @@ uint32_t mipt_make_grid_mesh(uint32_t n, float extent, float height, uint32_t se
     memcpy(v, vv.data(), vv.size() * sizeof(Vertex));
     memcpy(idx, ee.data(), ee.size() * 4);
     return (uint32_t)vv.size();
+}
+
+int mipt_rgbe_decode(const unsigned char* data, size_t size, float* rgb_out, uint32_t* width, uint32_t* height) {
+    if (!data || !width || !height) return MIPT_E_INVALID;
+    std::vector<float> rgb; int w = 0, h = 0;
+    if (!Rgbe::Decode(data, size, rgb, w, h)) return MIPT_E_INVALID;
+    *width = (uint32_t)w; *height = (uint32_t)h;
+    if (rgb_out) memcpy(rgb_out, rgb.data(), rgb.size() * sizeof(float));
+    return MIPT_OK;
+}
+size_t mipt_rgbe_encode(const float* rgb, uint32_t width, uint32_t height, unsigned char* out, size_t cap) {
+    if (!rgb || !width || !height) return 0;
+    std::vector<unsigned char> o = Rgbe::Encode(rgb, (int)width, (int)height);
+    if (out && cap >= o.size()) memcpy(out, o.data(), o.size());
+    return o.size();
 }
 
 }  // extern "C"

@@ -150,6 +150,12 @@ void     mipt_make_synthetic_sky(uint32_t w, uint32_t h, uint32_t seed, float* r
 /* synthetic displaced-grid stress mesh (n x n quads, heights = 4-octave value noise): returns vertex count */
 uint32_t mipt_make_grid_mesh(uint32_t n, float extent, float height, uint32_t seed, mipt_vertex* v, uint32_t* idx);
 
+/* Radiance RGBE (.hdr): the env-map file format on the input side of the path (Common/rgbe.c:93-106,134-190,327-412;
+ * read at DefaultScene/tracer.cpp:130-138).  decode: pass rgb_out NULL to query the size; returns 0 or MIPT_E_INVALID.
+ * encode: returns the byte count (call with out NULL to size the buffer). */
+int      mipt_rgbe_decode(const unsigned char* data, size_t size, float* rgb_out, uint32_t* width, uint32_t* height);
+size_t   mipt_rgbe_encode(const float* rgb, uint32_t width, uint32_t height, unsigned char* out, size_t cap);
+
 /* ---- device math self-test (used by the parity tests of the portable transcendentals) --------------------- */
 /* fn 0 sin 1 cos 2 atan2(a,b) 3 acos 4 x^(1/2.2) 5 x^5 6 x^10 ; host arrays */
 int  mipt_test_math(mipt_tracer*, int fn, const float* a, const float* b, uint32_t n, float* out);

@@ -1,0 +1,76 @@
+"""Multi-GPU sharding logic on CPU: world_size-2 gloo processes render disjoint frame subsets (sample striding,
+SURVEY 8e) into SUM buffers -- with the oracle standing in for the GPU -- and one reduce combines them."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_frames_for_rank_partition():
+    from cudapathtracer_amd.dist import frames_for_rank
+    for n in (0, 1, 5, 8, 4096):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                first, count, stride = frames_for_rank(10, n, r, world)
+                seen += [first + i * stride for i in range(count)]
+            assert sorted(seen) == list(range(10, 10 + n))
+    with pytest.raises(ValueError):
+        frames_for_rank(0, 4, 2, 2)
+
+
+WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tests"))
+import cudapathtracer_amd as pt
+from cudapathtracer_amd.dist import frames_for_rank, reduce_accumulation
+from oracle import orc
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+data = pt.builtin_scene(0)
+o = orc.Scene(data)
+W, H, N = 48, 32, 6
+s = pt.make_settings(pt.make_camera(**pt.CORNELL_CAMERA), W, H, 3)
+first, count, stride = frames_for_rank(0, N, rank, world)
+acc = np.zeros((H, W, 4), np.float32)
+for i in range(count):          # sum mode: acc += sample of frame first + i*stride
+    r = o.render(s, orc.ISECT_BRUTE, orc.RNG_NODE, orc.MATH_DET, first + i * stride, 1, acc=np.zeros((H, W, 4), np.float32), want_ldr=False, nthreads=2)
+    acc[..., :3] += r["sample"]
+mean = reduce_accumulation(torch.from_numpy(acc), N, dst=0)
+if rank == 0:
+    np.save(os.environ["OUT"], mean.numpy())
+else:
+    assert mean is None
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_sample_striding_matches_single_rank(tmp_path, ptlib, oracle):
+    out = str(tmp_path / "mean.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, REPO=ROOT, OUT=out, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    o = oracle.Scene(ptlib.builtin_scene(0))
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), 48, 32, 3)
+    ref = o.render(s, oracle.ISECT_BRUTE, oracle.RNG_NODE, oracle.MATH_DET, 0, 6, want_ldr=False)["acc"]   # running mean
+    assert (got[..., 3] == 1).all()
+    assert np.allclose(got[..., :3], ref[..., :3], rtol=1e-5, atol=1e-6)      # summation order differs

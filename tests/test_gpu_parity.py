@@ -98,8 +98,9 @@ def test_golden_render_crop(tracer, ptlib, oracle, name):
     assert np.abs(l[y0:y1, x0:x1].astype(int) - g["ldr"].astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("integrator", [0, 1], ids=["wavestack", "levelqueues"])
 @pytest.mark.parametrize("name,w,h,depth", [("cornell", 160, 96, 5), ("default", 128, 128, 7), ("cornell", 67, 33, 1), ("default", 64, 64, 12)])
-def test_frame_matches_oracle(tracer, ptlib, oracle, name, w, h, depth):
+def test_frame_matches_oracle(tracer, ptlib, oracle, name, w, h, depth, integrator):
     which, cam_kw, env, _, _ = MG.CONFIGS[name]
     data = MG.scene_data(name)
     sc = ptlib.Scene(tracer, data)
@@ -108,6 +109,7 @@ def test_frame_matches_oracle(tracer, ptlib, oracle, name, w, h, depth):
     s = ptlib.make_settings(ptlib.make_camera(**cam_kw), w, h, depth)
     acc, ldr = dev_buffers(tracer, w, h)
     tracer.set_option("count_pixel_rays", 1)
+    tracer.set_option("integrator", integrator)
     tracer.reset_counters()
     try:
         exp_acc = np.zeros((h, w, 4), np.float32)
@@ -125,6 +127,7 @@ def test_frame_matches_oracle(tracer, ptlib, oracle, name, w, h, depth):
             assert l[..., :3].max() <= 186 and (l[..., 3] == 255).all()
         assert tracer.counters().frames == 3
     finally:
+        tracer.set_option("integrator", 0)
         tracer.set_option("count_pixel_rays", 0)
         tracer.free(acc), tracer.free(ldr)
 
@@ -178,12 +181,18 @@ def test_tile_size_does_not_change_the_image(tracer, ptlib):
     acc, _ = dev_buffers(tracer, 200, 120, ldr=False)
     out = []
     try:
+        tracer.set_option("integrator", 1)          # tiles exist only in the level-synchronous integrator
         for tile in (0, 4096, 777, 64):
             tracer.set_option("tile_pixels", tile)
             tracer.reset_counters()
             tracer.render(sc, s, 3, 1, acc)
             out.append((tracer.last_sample(200 * 120), tracer.counters().rays))
+        tracer.set_option("integrator", 0)          # ... and the wave-stack integrator must agree with it
+        tracer.reset_counters()
+        tracer.render(sc, s, 3, 1, acc)
+        out.append((tracer.last_sample(200 * 120), tracer.counters().rays))
     finally:
+        tracer.set_option("integrator", 0)
         tracer.set_option("tile_pixels", 0)
         tracer.free(acc)
     for rgb, rays in out[1:]:
