@@ -166,6 +166,12 @@ int mipt_synchronize(mipt_tracer* t) {
     if (use(t)) return MIPT_E_HIP;
     HIPCHK(t, hipStreamSynchronize(t->stream));
     resolve_events(t);
+    unsigned long long flag = 0;
+    HIPCHK(t, hipMemcpy(&flag, t->stats + 39, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) {
+        hipMemset(t->stats + 39, 0, sizeof flag);
+        return fail(t, MIPT_E_LIMIT, "wave stack overflow: a frame lost rays (raise the per-wave capacity)");
+    }
     return MIPT_OK;
 }
 
@@ -350,8 +356,8 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
     uint32_t tile = npix;
     uint32_t wcap = 0;
     if (t->integrator == 0) {
-        // persistent wave stacks: 128 entries per recursion level per wave (see k_wavestack), independent of the viewport
-        wcap = 128u * std::max<uint32_t>(D, 1u) + 64u;
+        // persistent wave stacks: 256 entries per recursion level per wave (see k_wavestack), independent of the viewport
+        wcap = 256u * std::max<uint32_t>(D, 1u) + 256u;
         const size_t need = (size_t)persistentBlocks * 4 * wcap;
         if (t->wstackEntries < need) {
             free_queue(t->wstack); t->wstackEntries = 0;

@@ -18,7 +18,7 @@ constexpr int kBlock = 256;
 constexpr uint32_t kLeaf = 0x80000000u;
 constexpr uint32_t kTerm = 0xFFFFFFFFu;
 constexpr int kStackCap = 64;      // == kMaxBvhDepth of the builder
-constexpr int kLdsStack = 16;      // entries per lane kept in LDS; deeper entries spill to scratch
+constexpr int kLdsStack = 12;      // entries per lane kept in LDS; deeper entries spill to scratch
 
 struct HitRec { float t, u, v; int ref; int tri; bool front; };   // ref = reference index, tri = global triangle id
 
@@ -266,7 +266,7 @@ MIPT_DEV void add_sample(float* sample, uint32_t pix, v3 c) {
 // =================================================================================================================
 // Wavefront level kernel.  Persistent grid-stride over the input queue; every lane handles one ray per iteration.
 // =================================================================================================================
-constexpr uint32_t kLdsSceneVec = 1024;    // float4 slots (16 KiB) for an LDS-resident scene
+constexpr uint32_t kLdsSceneVec = 256;     // float4 slots (4 KiB) for an LDS-resident scene (the Cornell box needs 168)
 
 template <bool PRIMARY, bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock) k_level(LevelArgs A) {
@@ -356,23 +356,47 @@ void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s) {
 }
 
 // =================================================================================================================
-// Persistent wave-private work stacks.
+// Persistent wave-private work stacks with in-wave refill (the default integrator).
 //
 // The level-synchronous kernel above pays one returning atomic on ONE counter per wave-batch to append to the next
 // level's queue; on MI355X a single word sustains only ~90 such atomics per microsecond, which bounded every
 // non-final level (measured: profiles/r1).  Here nothing is shared between waves: a wave keeps its pending rays in
-// its own LIFO region of HBM (hot top in L2), pops 64 per iteration, and pushes the children back with the same
-// ballot/prefix compaction -- the "allocation" is a wave-uniform stack pointer.  Idle lanes are refilled with new
-// primary rays claimed 64 at a time from a frame-wide pixel counter (one atomic per refill), so lanes stay full until
-// the frame runs dry and one launch renders the whole frame.
+// its own LIFO region of HBM (hot top in L2) and pushes children with the same ballot/prefix compaction -- the
+// "allocation" is a wave-uniform stack pointer.  One launch renders the whole frame.
 //
-// Stack bound: entries are kept sorted by recursion level (primaries enter in the lowest lanes, children are pushed
-// in lane order), so when level-L rays are pushed every older level->=L ray has just been popped; each level holds at
-// most 128 entries, the stack at most 128 * (maxDepth - 1).
+// Lanes are kept busy in both halves of the work:
+//  * traversal: a lane whose ray has terminated parks its (ray, hit) record in a per-wave LDS shade queue and goes
+//    idle; once kRefill lanes are idle they are refilled together from the top of the wave's stack, or with new primary
+//    rays claimed from one frame-wide pixel counter (one atomic per refill), so short rays do not wait for the longest
+//    traversal in the wave;
+//  * shading: runs only on full batches of 64 parked records (or on what is left when the wave is starving), so hit
+//    and miss code never executes for a handful of lanes.
+// Rays are independent and carry their own RNG key (node id), so the order they are processed in does not change any
+// ray, only the order of the atomic adds into a pixel.
+//
+// Stack size: with strict 64-ray batches each recursion level holds <= 128 entries; out-of-order refill loosens that
+// (simulated worst case, every ray spawning two children: ~160 per level), so the host sizes the stack at
+// 256 * maxDepth + 256 entries per wave and the kernel raises an error flag instead of writing past it.
 // =================================================================================================================
+constexpr int kSqCap = 96;           // shade-queue entries per wave; a terminated ray that finds it full parks one round later
+constexpr int kSqWords = 16;         // dwords per entry, SoA by dword: conflict-free LDS access
+constexpr int kRefill = 8;           // refill once this many lanes are idle
+
 template <bool LDS_SCENE>
-__global__ void __launch_bounds__(kBlock) k_wavestack(StackArgs A) {
+MIPT_DEV void load_node(const float4* lds, const float4* glb, uint32_t cur, float4& n0, float4& n1, float4& n2, float4& n3) {
+    if constexpr (LDS_SCENE) { const float4* N = lds + (size_t)cur * 4; n0 = N[0]; n1 = N[1]; n2 = N[2]; n3 = N[3]; }
+    else { const float4* N = glb + (size_t)cur * 4; n0 = N[0]; n1 = N[1]; n2 = N[2]; n3 = N[3]; }
+}
+template <bool LDS_SCENE>
+MIPT_DEV void load_ref(const float4* lds, const float4* glb, uint32_t i, float4& a, float4& b, float4& c) {
+    if constexpr (LDS_SCENE) { const float4* T = lds + (size_t)i * 3; a = T[0]; b = T[1]; c = T[2]; }
+    else { const float4* T = glb + (size_t)i * 3; a = T[0]; b = T[1]; c = T[2]; }
+}
+
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    __shared__ float sqMem[(kBlock / 64) * kSqWords * kSqCap];
     __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneVec : 1];
     if (LDS_SCENE) {
         const uint32_t nn = A.S.nNodes * 4, nr = A.S.nRefs * 3;
@@ -380,75 +404,185 @@ __global__ void __launch_bounds__(kBlock) k_wavestack(StackArgs A) {
         for (uint32_t i = threadIdx.x; i < nr; i += kBlock) ldsScene[nn + i] = A.S.refs[i];
         __syncthreads();
     }
+    const float4* ldsNodes = ldsScene;
+    const float4* ldsRefs = ldsScene + (LDS_SCENE ? A.S.nNodes * 4 : 0);
     const uint32_t lane = __lane_id();
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + wv;
     const size_t wbase = (size_t)wave * A.cap;
     float4* __restrict__ qa = A.stack.a + wbase;
     float4* __restrict__ qb = A.stack.b + wbase;
     float4* __restrict__ qc = A.stack.c + wbase;
+    float* sq = sqMem + wv * (kSqWords * kSqCap);
+    uint32_t* sqi = reinterpret_cast<uint32_t*>(sq);
     const unsigned long long below = (1ull << lane) - 1ull;
-    uint32_t sp = 0;                 // wave-uniform
-    bool more = true;                // wave-uniform: the frame may still have unclaimed pixels
-    uint32_t traced = 0;             // per-lane ray count
+
+    // wave-uniform state
+    uint32_t sp = 0, sqn = 0;
+    bool more = true;
+    // per-lane traversal state
+    bool active = false;
+    v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), beta = mk3(0, 0, 0);
+    uint32_t pix = 0, node = 1, s0 = 0;
+    RayPre r = ray_pre(o, d);
+    HitRec h; h.t = __builtin_inff(); h.u = h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
+    uint32_t cur = kTerm;
+    Stack st; st.lds = ldsStack + threadIdx.x; st.sp = 0;
+    uint32_t traced = 0;
+
     while (true) {
-        const uint32_t take = sp < 64u ? sp : 64u;
-        uint32_t got = 0, pbase = 0;
-        if (more && take < 64u) {
-            const uint32_t want = 64u - take;
-            if (lane == 0) pbase = atomicAdd(A.pixCounter, want);
-            pbase = __builtin_amdgcn_readfirstlane(pbase);
-            got = pbase < A.npix ? (A.npix - pbase < want ? A.npix - pbase : want) : 0u;
-            if (got < want) more = false;
-        }
-        if (take + got == 0) break;
-        sp -= take;
-        // lanes [0, got) start new primary rays, lanes [got, got + take) continue the rays on top of the stack
-        const bool active = lane < got + take;
-        v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), beta = mk3(1.f, 1.f, 1.f);
-        uint32_t pix = 0, node = 1, s0 = 0;
-        bool has = false;
-        Bounce b;
-        if (active) {
-            if (lane < got) {
-                pix = A.pix0 + pbase + lane;
-                gen_primary(A.F, pix, o, d, s0);
-            } else {
-                const uint32_t e = sp + (lane - got);
-                float4 ra = qa[e], rb = qb[e], rc = qc[e];
-                o = xyz(ra); d = mk3(ra.w, rb.x, rb.y); beta = mk3(rb.z, rb.w, rc.x);
-                pix = __float_as_uint(rc.y); node = __float_as_uint(rc.z); s0 = __float_as_uint(rc.w);
+        const unsigned long long actMask = __ballot(active);
+        const uint32_t idle = 64u - (uint32_t)__popcll(actMask);
+
+        // ---- A. shade a full batch of parked records (or whatever is parked when the wave is starving) -----------
+        const bool starving = idle >= (uint32_t)kRefill && sp == 0 && !more;
+        if (sqn >= 64u || (starving && sqn > 0u)) {
+            const uint32_t n = sqn < 64u ? sqn : 64u;
+            sqn -= n;
+            bool has = false;
+            Bounce b;
+            uint32_t spix = 0, snode = 0, ss0 = 0;
+            if (lane < n) {
+                const uint32_t e = sqn + lane;
+                v3 P = mk3(sq[0 * kSqCap + e], sq[1 * kSqCap + e], sq[2 * kSqCap + e]);
+                v3 sd = mk3(sq[3 * kSqCap + e], sq[4 * kSqCap + e], sq[5 * kSqCap + e]);
+                v3 sb = mk3(sq[6 * kSqCap + e], sq[7 * kSqCap + e], sq[8 * kSqCap + e]);
+                spix = sqi[9 * kSqCap + e]; snode = sqi[10 * kSqCap + e]; ss0 = sqi[11 * kSqCap + e];
+                const float su = sq[12 * kSqCap + e], sv = sq[13 * kSqCap + e];
+                const uint32_t tf = sqi[14 * kSqCap + e];
+                if (tf == 0xFFFFFFFFu) {
+                    add_sample(A.sample, spix, sb * on_miss(A.S, sd));
+                } else {
+                    const bool front = (tf >> 31) != 0;
+                    const uint32_t tri = tf & 0x7FFFFFFFu;
+                    const float4* Sh = A.S.shade + (size_t)tri * 3;
+                    float4 n0 = Sh[0], n1 = Sh[1], n2 = Sh[2];
+                    float w0 = 1 - su - sv, w1 = su, w2 = sv;
+                    v3 hn = xyz(n0) * w0 + xyz(n1) * w1 + xyz(n2) * w2;
+                    Surface sf; sf.P = P; sf.N = front ? hn : -hn; sf.mesh = __float_as_uint(n0.w);
+                    Material mat = load_material(A.S, sf.mesh);
+                    add_sample(A.sample, spix, sb * (mat.emissive * mat.emissiveStrength));
+                    const uint32_t level = 31u - (uint32_t)__clz((int)snode);     // root = 1 -> level 0
+                    if (level + 1 < A.F.maxDepth) {                                // children have ttl-1 > 0 (CUDATracerProg.cu:433)
+                        Lcg rng; rng.state = node_seed(ss0, snode);
+                        b = shade_hit(mat, sf, sd, front, rng);
+                        b.f1 = sb * b.f1; b.f2 = sb * b.f2;
+                        has = true;
+                    }
+                }
             }
-            traced++;
-            if (A.pixelRays) atomicAdd(A.pixelRays + pix, 1u);
-            HitRec h = LDS_SCENE ? traverse((const float4*)ldsScene, (const float4*)ldsScene + A.S.nNodes * 4, o, d, ldsStack + threadIdx.x)
-                                 : traverse(A.S.nodes, A.S.refs, o, d, ldsStack + threadIdx.x);
-            if (h.ref < 0) {
-                add_sample(A.sample, pix, beta * on_miss(A.S, d));
-            } else {
-                Surface sf = surface_at(A.S, o, d, h);
-                Material mat = load_material(A.S, sf.mesh);
-                add_sample(A.sample, pix, beta * (mat.emissive * mat.emissiveStrength));
-                const uint32_t level = 31u - (uint32_t)__clz((int)node);       // root = 1 -> level 0
-                if (level + 1 < A.F.maxDepth) {                                  // children have ttl-1 > 0 (CUDATracerProg.cu:433)
-                    Lcg rng; rng.state = node_seed(s0, node);
-                    b = shade_hit(mat, sf, d, h.front, rng);
-                    b.f1 = beta * b.f1; b.f2 = beta * b.f2;
-                    has = true;
+            const unsigned long long m = __ballot(has);
+            if (m) {
+                const uint32_t total = 2u * (uint32_t)__popcll(m);
+                if (sp + total > A.cap) {
+                    if (lane == 0) atomicOr(A.stats + 39, 1ull);       // overflow: reported by the host, never written past
+                } else {
+                    const uint32_t w = sp + 2u * (uint32_t)__popcll(m & below);
+                    if (has) {
+                        qa[w] = make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x);
+                        qb[w] = make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y);
+                        qc[w] = make_float4(b.f1.z, __uint_as_float(spix), __uint_as_float(snode * 2u), __uint_as_float(ss0));
+                        qa[w + 1] = make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x);
+                        qb[w + 1] = make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y);
+                        qc[w + 1] = make_float4(b.f2.z, __uint_as_float(spix), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0));
+                    }
+                    sp += total;
+                }
+            }
+            continue;
+        }
+
+        // ---- B. refill idle lanes: new primaries in the lowest ranks, then the top of the wave's stack --------------
+        if (idle >= (uint32_t)kRefill && (sp > 0u || more)) {
+            const uint32_t take = sp < idle ? sp : idle;
+            uint32_t got = 0, pbase = 0;
+            if (more && take < idle) {
+                const uint32_t want = idle - take;
+                if (lane == 0) pbase = atomicAdd(A.pixCounter, want);
+                pbase = __builtin_amdgcn_readfirstlane(pbase);
+                got = pbase < A.npix ? (A.npix - pbase < want ? A.npix - pbase : want) : 0u;
+                if (got < want) more = false;
+            }
+            sp -= take;
+            if (!active) {
+                const uint32_t rank = (uint32_t)__popcll(~actMask & below);
+                if (rank < got + take) {
+                    if (rank < got) {
+                        pix = A.pix0 + pbase + rank; node = 1; beta = mk3(1.f, 1.f, 1.f);
+                        gen_primary(A.F, pix, o, d, s0);
+                    } else {
+                        const uint32_t e = sp + (rank - got);
+                        float4 ra = qa[e], rb = qb[e], rc = qc[e];
+                        o = xyz(ra); d = mk3(ra.w, rb.x, rb.y); beta = mk3(rb.z, rb.w, rc.x);
+                        pix = __float_as_uint(rc.y); node = __float_as_uint(rc.z); s0 = __float_as_uint(rc.w);
+                    }
+                    r = ray_pre(o, d);
+                    h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
+                    st.sp = 0; st.push(kTerm);
+                    cur = 0;
+                    active = true;
+                    traced++;
+                    if (A.pixelRays) atomicAdd(A.pixelRays + pix, 1u);
                 }
             }
         }
-        const unsigned long long m = __ballot(has);
-        if (m) {
-            const uint32_t w = sp + 2u * (uint32_t)__popcll(m & below);
-            if (has) {
-                qa[w] = make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x);
-                qb[w] = make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y);
-                qc[w] = make_float4(b.f1.z, __uint_as_float(pix), __uint_as_float(node * 2u), __uint_as_float(s0));
-                qa[w + 1] = make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x);
-                qb[w + 1] = make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y);
-                qc[w + 1] = make_float4(b.f2.z, __uint_as_float(pix), __uint_as_float(node * 2u + 1u), __uint_as_float(s0));
+
+        // ---- C. done when nothing is in flight, parked, stacked or left in the frame --------------------------------
+        if (!__ballot(active)) {
+            if (sqn == 0u) break;
+            continue;
+        }
+
+        // ---- D. one traversal round: descend to the next leaf, test it, park the rays that have terminated ----------
+        if (active) {
+            while (!(cur & kLeaf)) {
+                float4 n0, n1, n2, n3;
+                load_node<LDS_SCENE>(ldsNodes, A.S.nodes, cur, n0, n1, n2, n3);
+                float t0, t1;
+                bool h0 = slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, h.t, t0);
+                bool h1 = slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, h.t, t1);
+                uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
+                if (h0 || h1) {
+                    uint32_t first = h0 ? c0 : c1;
+                    if (h0 && h1) {
+                        uint32_t second = c1;
+                        if (t1 < t0) { first = c1; second = c0; }
+                        st.push(second);
+                    }
+                    cur = first;
+                } else {
+                    cur = st.pop();
+                }
             }
-            sp += 2u * (uint32_t)__popcll(m);
+            if (cur != kTerm) {
+                uint32_t cnt = (cur >> 27) & 0xFu, first = cur & 0x07FFFFFFu;
+                for (uint32_t i = first; i < first + cnt; i++) {
+                    float4 a, b, c;
+                    load_ref<LDS_SCENE>(ldsRefs, A.S.refs, i, a, b, c);
+                    float tt, uu, vv; bool ff;
+                    int id = (int)__float_as_uint(a.w);
+                    if (mt_test(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) { h.t = tt; h.u = uu; h.v = vv; h.front = ff; h.ref = (int)i; h.tri = id; }
+                }
+                cur = st.pop();
+            }
+        }
+        bool fin = active && cur == kTerm;
+        unsigned long long fm = __ballot(fin);
+        if (fm) {
+            const uint32_t e = sqn + (uint32_t)__popcll(fm & below);
+            fin = fin && e < (uint32_t)kSqCap;          // no room: stay terminated-but-unparked until the queue is shaded
+            fm = __ballot(fin);
+            if (fin) {
+                v3 P = o + d * h.t;                                   // tail of NearestIntersectSubset (:294)
+                sq[0 * kSqCap + e] = P.x; sq[1 * kSqCap + e] = P.y; sq[2 * kSqCap + e] = P.z;
+                sq[3 * kSqCap + e] = d.x; sq[4 * kSqCap + e] = d.y; sq[5 * kSqCap + e] = d.z;
+                sq[6 * kSqCap + e] = beta.x; sq[7 * kSqCap + e] = beta.y; sq[8 * kSqCap + e] = beta.z;
+                sqi[9 * kSqCap + e] = pix; sqi[10 * kSqCap + e] = node; sqi[11 * kSqCap + e] = s0;
+                sq[12 * kSqCap + e] = h.u; sq[13 * kSqCap + e] = h.v;
+                sqi[14 * kSqCap + e] = h.tri < 0 ? 0xFFFFFFFFu : ((uint32_t)h.tri | (h.front ? 0x80000000u : 0u));
+                active = false;
+            }
+            sqn += (uint32_t)__popcll(fm);
         }
     }
     // one counter update per wave
