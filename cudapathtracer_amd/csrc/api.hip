@@ -30,7 +30,8 @@ struct mipt_tracer {
     int64_t queueBudgetMB = 6144;
     int64_t rngMode = MIPT_RNG_NODE;
     int64_t countPixelRays = 0;
-    int64_t blocksPerCU = 8;
+    int64_t blocksPerCU = 4;         // resident 256-thread blocks per CU of the persistent kernels
+    int64_t refillLanes = 8;
     int64_t profileLevels = 0;
     int64_t integrator = 0;          // 0 persistent wave stacks, 1 level-synchronous queues
     // work buffers
@@ -182,6 +183,7 @@ int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
     else if (k == "queue_budget_mb") { if (v < 1) return fail(t, MIPT_E_INVALID, "queue_budget_mb < 1"); t->queueBudgetMB = v; }
     else if (k == "rng_mode") { if (v != MIPT_RNG_NODE && v != MIPT_RNG_DFS) return fail(t, MIPT_E_INVALID, "bad rng_mode"); t->rngMode = v; }
     else if (k == "count_pixel_rays") t->countPixelRays = v ? 1 : 0;
+    else if (k == "refill_lanes") { if (v < 1 || v > 64) return fail(t, MIPT_E_INVALID, "refill_lanes out of range"); t->refillLanes = v; }
     else if (k == "profile_levels") t->profileLevels = v ? 1 : 0;
     else if (k == "integrator") { if (v != 0 && v != 1) return fail(t, MIPT_E_INVALID, "integrator must be 0 (wave stacks) or 1 (level queues)"); t->integrator = v; }
     else if (k == "blocks_per_cu") { if (v < 1 || v > 32) return fail(t, MIPT_E_INVALID, "blocks_per_cu out of range"); t->blocksPerCU = v; }
@@ -395,7 +397,7 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
         if (t->integrator == 0 && D >= 1) {
             HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), t->stream));
             StackArgs SA;
-            SA.S = sc->dev; SA.F = A.F; SA.stack = t->wstack; SA.cap = wcap; SA.pixCounter = t->counts;
+            SA.S = sc->dev; SA.F = A.F; SA.stack = t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes; SA.pixCounter = t->counts;
             SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npix;
             mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
             if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, t->stream)); }

@@ -49,7 +49,8 @@ struct LevelArgs {
 struct StackArgs {
     SceneDev S; FrameDev F;
     Queue stack;                 // waves * cap entries, wave w owns [w*cap, (w+1)*cap)
-    uint32_t cap;                // >= 128 * maxDepth
+    uint32_t refill;             // refill idle lanes once this many are idle (1..64)
+    uint32_t cap;                // entries per wave
     uint32_t* pixCounter;        // next unclaimed pixel of the frame (reset to 0 before the launch)
     float* sample; uint32_t* pixelRays; unsigned long long* stats;
     uint32_t pix0, npix;

@@ -68,20 +68,13 @@ MIPT_DEV bool mt_test(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, int id, int b
 }
 
 // Traversal stack: the first kLdsStack entries of every lane live in LDS (bank = lane, conflict-free), deeper
-// entries in a private scratch array that is only touched by unusually deep paths.
-struct Stack {
-    uint32_t* lds;                 // &block_lds[threadIdx.x]
-    uint32_t deep[kStackCap - kLdsStack];
-    int sp;
-    MIPT_DEV void push(uint32_t x) {
-        if (sp < kLdsStack) lds[sp * kBlock] = x; else deep[sp - kLdsStack] = x;
-        sp++;
-    }
-    MIPT_DEV uint32_t pop() {
-        sp--;
-        return sp < kLdsStack ? lds[sp * kBlock] : deep[sp - kLdsStack];
-    }
-};
+// entries in a private scratch array that is only touched by unusually deep paths.  The stack pointer is a plain
+// register and the two halves are reached through separate branches: folding them into one struct/pointer select
+// puts the pointer itself in scratch and turns every pop into a flat load behind a scratch load.
+#define MIPT_STACK_PUSH(lds_, deep_, sp_, x_)                                              \
+    do { if ((sp_) < kLdsStack) (lds_)[(sp_) * kBlock] = (x_); else (deep_)[(sp_) - kLdsStack] = (x_); (sp_)++; } while (0)
+#define MIPT_STACK_POP(lds_, deep_, sp_, out_)                                             \
+    do { (sp_)--; if ((sp_) < kLdsStack) (out_) = (lds_)[(sp_) * kBlock]; else (out_) = (deep_)[(sp_) - kLdsStack]; } while (0)
 
 // Closest hit (TraceRay, CUDATracerProg.cu:543-794) on the flat scene BVH.  Near child first, far child pushed;
 // leaves are tested when they become current; hitT shrinks as hits are found and culls later box tests.
@@ -92,8 +85,9 @@ template <typename NodePtr, typename RefPtr>
 MIPT_DEV HitRec traverse(NodePtr nodes, RefPtr refs, v3 o, v3 d, uint32_t* ldsStack) {
     RayPre r = ray_pre(o, d);
     HitRec h; h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
-    Stack st; st.lds = ldsStack; st.sp = 0;
-    st.push(kTerm);
+    uint32_t deep[kStackCap - kLdsStack];
+    int tsp = 0;
+    MIPT_STACK_PUSH(ldsStack, deep, tsp, kTerm);
     uint32_t cur = 0;
     while (true) {
         while (!(cur & kLeaf)) {
@@ -108,11 +102,11 @@ MIPT_DEV HitRec traverse(NodePtr nodes, RefPtr refs, v3 o, v3 d, uint32_t* ldsSt
                 if (h0 && h1) {
                     uint32_t second = c1;
                     if (t1 < t0) { first = c1; second = c0; }
-                    st.push(second);
+                    MIPT_STACK_PUSH(ldsStack, deep, tsp, second);
                 }
                 cur = first;
             } else {
-                cur = st.pop();
+                MIPT_STACK_POP(ldsStack, deep, tsp, cur);
             }
         }
         if (cur == kTerm) break;
@@ -124,7 +118,7 @@ MIPT_DEV HitRec traverse(NodePtr nodes, RefPtr refs, v3 o, v3 d, uint32_t* ldsSt
             int id = (int)__float_as_uint(a.w);
             if (mt_test(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) { h.t = tt; h.u = uu; h.v = vv; h.front = ff; h.ref = (int)i; h.tri = id; }
         }
-        cur = st.pop();
+        MIPT_STACK_POP(ldsStack, deep, tsp, cur);
     }
     return h;
 }
@@ -380,7 +374,6 @@ void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s) {
 // =================================================================================================================
 constexpr int kSqCap = 96;           // shade-queue entries per wave; a terminated ray that finds it full parks one round later
 constexpr int kSqWords = 16;         // dwords per entry, SoA by dword: conflict-free LDS access
-constexpr int kRefill = 8;           // refill once this many lanes are idle
 
 template <bool LDS_SCENE>
 MIPT_DEV void load_node(const float4* lds, const float4* glb, uint32_t cur, float4& n0, float4& n1, float4& n2, float4& n3) {
@@ -427,7 +420,9 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     RayPre r = ray_pre(o, d);
     HitRec h; h.t = __builtin_inff(); h.u = h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
     uint32_t cur = kTerm;
-    Stack st; st.lds = ldsStack + threadIdx.x; st.sp = 0;
+    uint32_t* const lstk = ldsStack + threadIdx.x;
+    uint32_t deep[kStackCap - kLdsStack];
+    int tsp = 0;
     uint32_t traced = 0;
 
     while (true) {
@@ -435,7 +430,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
         const uint32_t idle = 64u - (uint32_t)__popcll(actMask);
 
         // ---- A. shade a full batch of parked records (or whatever is parked when the wave is starving) -----------
-        const bool starving = idle >= (uint32_t)kRefill && sp == 0 && !more;
+        const bool starving = idle >= A.refill && sp == 0 && !more;
         if (sqn >= 64u || (starving && sqn > 0u)) {
             const uint32_t n = sqn < 64u ? sqn : 64u;
             sqn -= n;
@@ -493,7 +488,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
         }
 
         // ---- B. refill idle lanes: new primaries in the lowest ranks, then the top of the wave's stack --------------
-        if (idle >= (uint32_t)kRefill && (sp > 0u || more)) {
+        if (idle >= A.refill && (sp > 0u || more)) {
             const uint32_t take = sp < idle ? sp : idle;
             uint32_t got = 0, pbase = 0;
             if (more && take < idle) {
@@ -518,7 +513,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     }
                     r = ray_pre(o, d);
                     h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
-                    st.sp = 0; st.push(kTerm);
+                    tsp = 0; MIPT_STACK_PUSH(lstk, deep, tsp, kTerm);
                     cur = 0;
                     active = true;
                     traced++;
@@ -547,11 +542,11 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     if (h0 && h1) {
                         uint32_t second = c1;
                         if (t1 < t0) { first = c1; second = c0; }
-                        st.push(second);
+                        MIPT_STACK_PUSH(lstk, deep, tsp, second);
                     }
                     cur = first;
                 } else {
-                    cur = st.pop();
+                    MIPT_STACK_POP(lstk, deep, tsp, cur);
                 }
             }
             if (cur != kTerm) {
@@ -563,7 +558,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     int id = (int)__float_as_uint(a.w);
                     if (mt_test(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) { h.t = tt; h.u = uu; h.v = vv; h.front = ff; h.ref = (int)i; h.tri = id; }
                 }
-                cur = st.pop();
+                MIPT_STACK_POP(lstk, deep, tsp, cur);
             }
         }
         bool fin = active && cur == kTerm;
