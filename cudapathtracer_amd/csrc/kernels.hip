@@ -18,7 +18,7 @@ constexpr int kBlock = 256;
 constexpr uint32_t kLeaf = 0x80000000u;
 constexpr uint32_t kTerm = 0xFFFFFFFFu;
 constexpr int kStackCap = 64;      // == kMaxBvhDepth of the builder
-constexpr int kLdsStack = 12;      // entries per lane kept in LDS; deeper entries spill to scratch
+constexpr int kLdsStack = 8;       // entries per lane kept in LDS; deeper entries spill to scratch
 
 struct HitRec { float t, u, v; int ref; int tri; bool front; };   // ref = reference index, tri = global triangle id
 
@@ -74,7 +74,10 @@ MIPT_DEV bool mt_test(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, int id, int b
 #define MIPT_STACK_PUSH(lds_, deep_, sp_, x_)                                              \
     do { if ((sp_) < kLdsStack) (lds_)[(sp_) * kBlock] = (x_); else (deep_)[(sp_) - kLdsStack] = (x_); (sp_)++; } while (0)
 #define MIPT_STACK_POP(lds_, deep_, sp_, out_)                                             \
-    do { (sp_)--; if ((sp_) < kLdsStack) (out_) = (lds_)[(sp_) * kBlock]; else (out_) = (deep_)[(sp_) - kLdsStack]; } while (0)
+    do { (sp_)--;                                                                            \
+         if ((sp_) < kLdsStack) { (out_) = (lds_)[(sp_) * kBlock]; asm volatile("" : "+v"(out_)); }      /* keep ds_read ... */ \
+         else { (out_) = (deep_)[(sp_) - kLdsStack]; asm volatile("" : "+v"(out_)); }                    /* ... and scratch_load apart */ \
+    } while (0)
 
 // Closest hit (TraceRay, CUDATracerProg.cu:543-794) on the flat scene BVH.  Near child first, far child pushed;
 // leaves are tested when they become current; hitT shrinks as hits are found and culls later box tests.
@@ -372,7 +375,9 @@ void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s) {
 // (simulated worst case, every ray spawning two children: ~160 per level), so the host sizes the stack at
 // 256 * maxDepth + 256 entries per wave and the kernel raises an error flag instead of writing past it.
 // =================================================================================================================
-constexpr int kSqCap = 96;           // shade-queue entries per wave; a terminated ray that finds it full parks one round later
+// shade-queue entries per wave (a terminated ray that finds it full parks one round later); sized so that a
+// 256-thread block uses exactly a quarter of the CU's 160 KiB: 4 x cap x 64 B + 8 KiB traversal stacks (+ 4 KiB scene)
+template <bool LDS_SCENE> struct SqCap { static constexpr int value = LDS_SCENE ? 112 : 128; };
 constexpr int kSqWords = 16;         // dwords per entry, SoA by dword: conflict-free LDS access
 
 template <bool LDS_SCENE>
@@ -388,6 +393,7 @@ MIPT_DEV void load_ref(const float4* lds, const float4* glb, uint32_t i, float4&
 
 template <bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
+    constexpr int kSqCap = SqCap<LDS_SCENE>::value;
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
     __shared__ float sqMem[(kBlock / 64) * kSqWords * kSqCap];
     __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneVec : 1];
@@ -411,7 +417,9 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     const unsigned long long below = (1ull << lane) - 1ull;
 
     // wave-uniform state
-    uint32_t sp = 0, sqn = 0;
+    uint32_t sp = 0;
+    uint32_t nF = 0, nT = 0;          // parked records: "full" ones (will spawn children) fill the queue from slot 0 up,
+                                      // "terminal" ones (miss, or hit at the last level: emission only) from the top down
     bool more = true;
     // per-lane traversal state
     bool active = false;
@@ -428,62 +436,72 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     while (true) {
         const unsigned long long actMask = __ballot(active);
         const uint32_t idle = 64u - (uint32_t)__popcll(actMask);
-
-        // ---- A. shade a full batch of parked records (or whatever is parked when the wave is starving) -----------
         const bool starving = idle >= A.refill && sp == 0 && !more;
-        if (sqn >= 64u || (starving && sqn > 0u)) {
-            const uint32_t n = sqn < 64u ? sqn : 64u;
-            sqn -= n;
-            bool has = false;
+        const bool pressure = nF + nT > (uint32_t)kSqCap - 32u;      // little room left for rays that terminate next
+
+        // ---- A1. shade a batch of "full" records: every lane runs the whole bounce and pushes two children ----------
+        if (nF >= 64u || (nF > 0u && (starving || (pressure && nF >= nT)))) {
+            const uint32_t n = nF < 64u ? nF : 64u;
+            nF -= n;
+            const bool has = lane < n;
             Bounce b;
             uint32_t spix = 0, snode = 0, ss0 = 0;
-            if (lane < n) {
-                const uint32_t e = sqn + lane;
+            if (has) {
+                const uint32_t e = nF + lane;
                 v3 P = mk3(sq[0 * kSqCap + e], sq[1 * kSqCap + e], sq[2 * kSqCap + e]);
                 v3 sd = mk3(sq[3 * kSqCap + e], sq[4 * kSqCap + e], sq[5 * kSqCap + e]);
                 v3 sb = mk3(sq[6 * kSqCap + e], sq[7 * kSqCap + e], sq[8 * kSqCap + e]);
                 spix = sqi[9 * kSqCap + e]; snode = sqi[10 * kSqCap + e]; ss0 = sqi[11 * kSqCap + e];
                 const float su = sq[12 * kSqCap + e], sv = sq[13 * kSqCap + e];
                 const uint32_t tf = sqi[14 * kSqCap + e];
+                const bool front = (tf >> 31) != 0;
+                const uint32_t tri = tf & 0x7FFFFFFFu;
+                const float4* Sh = A.S.shade + (size_t)tri * 3;
+                float4 n0 = Sh[0], n1 = Sh[1], n2 = Sh[2];
+                float w0 = 1 - su - sv, w1 = su, w2 = sv;
+                v3 hn = xyz(n0) * w0 + xyz(n1) * w1 + xyz(n2) * w2;
+                Surface sf; sf.P = P; sf.N = front ? hn : -hn; sf.mesh = __float_as_uint(n0.w);
+                Material mat = load_material(A.S, sf.mesh);
+                add_sample(A.sample, spix, sb * (mat.emissive * mat.emissiveStrength));
+                Lcg rng; rng.state = node_seed(ss0, snode);
+                b = shade_hit(mat, sf, sd, front, rng);
+                b.f1 = sb * b.f1; b.f2 = sb * b.f2;
+            }
+            const uint32_t total = 2u * n;
+            if (sp + total > A.cap) {
+                if (lane == 0) atomicOr(A.stats + 39, 1ull);       // overflow: reported by the host, never written past
+            } else {
+                if (has) {
+                    const uint32_t w = sp + 2u * lane;
+                    qa[w] = make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x);
+                    qb[w] = make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y);
+                    qc[w] = make_float4(b.f1.z, __uint_as_float(spix), __uint_as_float(snode * 2u), __uint_as_float(ss0));
+                    qa[w + 1] = make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x);
+                    qb[w + 1] = make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y);
+                    qc[w + 1] = make_float4(b.f2.z, __uint_as_float(spix), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0));
+                }
+                sp += total;
+            }
+            continue;
+        }
+        // ---- A2. a batch of terminal records: miss radiance, or the emission of a hit at the last level -------------
+        if (nT >= 64u || (nT > 0u && (starving || pressure))) {
+            const uint32_t n = nT < 64u ? nT : 64u;
+            if (lane < n) {
+                const uint32_t e = (uint32_t)kSqCap - nT + lane;
+                v3 sd = mk3(sq[3 * kSqCap + e], sq[4 * kSqCap + e], sq[5 * kSqCap + e]);
+                v3 sb = mk3(sq[6 * kSqCap + e], sq[7 * kSqCap + e], sq[8 * kSqCap + e]);
+                const uint32_t spix = sqi[9 * kSqCap + e];
+                const uint32_t tf = sqi[14 * kSqCap + e];
                 if (tf == 0xFFFFFFFFu) {
                     add_sample(A.sample, spix, sb * on_miss(A.S, sd));
                 } else {
-                    const bool front = (tf >> 31) != 0;
-                    const uint32_t tri = tf & 0x7FFFFFFFu;
-                    const float4* Sh = A.S.shade + (size_t)tri * 3;
-                    float4 n0 = Sh[0], n1 = Sh[1], n2 = Sh[2];
-                    float w0 = 1 - su - sv, w1 = su, w2 = sv;
-                    v3 hn = xyz(n0) * w0 + xyz(n1) * w1 + xyz(n2) * w2;
-                    Surface sf; sf.P = P; sf.N = front ? hn : -hn; sf.mesh = __float_as_uint(n0.w);
-                    Material mat = load_material(A.S, sf.mesh);
+                    const uint32_t mesh = __float_as_uint(A.S.shade[(size_t)(tf & 0x7FFFFFFFu) * 3].w);
+                    Material mat = load_material(A.S, mesh);
                     add_sample(A.sample, spix, sb * (mat.emissive * mat.emissiveStrength));
-                    const uint32_t level = 31u - (uint32_t)__clz((int)snode);     // root = 1 -> level 0
-                    if (level + 1 < A.F.maxDepth) {                                // children have ttl-1 > 0 (CUDATracerProg.cu:433)
-                        Lcg rng; rng.state = node_seed(ss0, snode);
-                        b = shade_hit(mat, sf, sd, front, rng);
-                        b.f1 = sb * b.f1; b.f2 = sb * b.f2;
-                        has = true;
-                    }
                 }
             }
-            const unsigned long long m = __ballot(has);
-            if (m) {
-                const uint32_t total = 2u * (uint32_t)__popcll(m);
-                if (sp + total > A.cap) {
-                    if (lane == 0) atomicOr(A.stats + 39, 1ull);       // overflow: reported by the host, never written past
-                } else {
-                    const uint32_t w = sp + 2u * (uint32_t)__popcll(m & below);
-                    if (has) {
-                        qa[w] = make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x);
-                        qb[w] = make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y);
-                        qc[w] = make_float4(b.f1.z, __uint_as_float(spix), __uint_as_float(snode * 2u), __uint_as_float(ss0));
-                        qa[w + 1] = make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x);
-                        qb[w + 1] = make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y);
-                        qc[w + 1] = make_float4(b.f2.z, __uint_as_float(spix), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0));
-                    }
-                    sp += total;
-                }
-            }
+            nT -= n;
             continue;
         }
 
@@ -524,7 +542,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
 
         // ---- C. done when nothing is in flight, parked, stacked or left in the frame --------------------------------
         if (!__ballot(active)) {
-            if (sqn == 0u) break;
+            if (nF + nT == 0u) break;
             continue;
         }
 
@@ -564,10 +582,13 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
         bool fin = active && cur == kTerm;
         unsigned long long fm = __ballot(fin);
         if (fm) {
-            const uint32_t e = sqn + (uint32_t)__popcll(fm & below);
-            fin = fin && e < (uint32_t)kSqCap;          // no room: stay terminated-but-unparked until the queue is shaded
-            fm = __ballot(fin);
+            // no room: stay terminated-but-unparked until the queue has been drained
+            fin = fin && nF + nT + (uint32_t)__popcll(fm & below) < (uint32_t)kSqCap;
+            const uint32_t level = 31u - (uint32_t)__clz((int)node);             // root = 1 -> level 0
+            const bool term = h.tri < 0 || level + 1 >= A.F.maxDepth;             // children would have ttl 0 (CUDATracerProg.cu:433)
+            const unsigned long long mF = __ballot(fin && !term), mT = __ballot(fin && term);
             if (fin) {
+                const uint32_t e = term ? (uint32_t)kSqCap - 1u - (nT + (uint32_t)__popcll(mT & below)) : nF + (uint32_t)__popcll(mF & below);
                 v3 P = o + d * h.t;                                   // tail of NearestIntersectSubset (:294)
                 sq[0 * kSqCap + e] = P.x; sq[1 * kSqCap + e] = P.y; sq[2 * kSqCap + e] = P.z;
                 sq[3 * kSqCap + e] = d.x; sq[4 * kSqCap + e] = d.y; sq[5 * kSqCap + e] = d.z;
@@ -577,7 +598,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 sqi[14 * kSqCap + e] = h.tri < 0 ? 0xFFFFFFFFu : ((uint32_t)h.tri | (h.front ? 0x80000000u : 0u));
                 active = false;
             }
-            sqn += (uint32_t)__popcll(fm);
+            nF += (uint32_t)__popcll(mF); nT += (uint32_t)__popcll(mT);
         }
     }
     // one counter update per wave
