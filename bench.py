@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU oracle budget (0 disables cpu_baseline)")
     p.add_argument("--tile-pixels", type=int, default=0)
     p.add_argument("--integrator", type=int, default=0, help="0 persistent wave stacks (default), 1 level-synchronous queues")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (default); gloo = rehearsal of the N>1 flow through host memory")
     p.add_argument("--traffic-gb", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC run (GB)")
     return p.parse_args()
 
@@ -88,9 +89,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    local = local % max(torch.cuda.device_count(), 1)      # rehearsals may put several ranks on one GPU
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     if a.gpus != world and rank == 0:
         print(f"note: --gpus {a.gpus} but WORLD_SIZE {world}; using {world} process(es)", file=sys.stderr)
     import cudapathtracer_amd as pt
@@ -132,7 +137,8 @@ def main():
         step(i)
     if world > 1:   # warm the RCCL path too, then start the timed run from a clean sum buffer
         t.synchronize()
-        dist.reduce(acc.clone(), dst=0, op=dist.ReduceOp.SUM)
+        warm = acc.clone() if a.backend == "nccl" else acc.cpu()
+        dist.reduce(warm, dst=0, op=dist.ReduceOp.SUM)
         acc.zero_()
     barrier()
     t.reset_counters()
@@ -143,8 +149,10 @@ def main():
         step(a.warmup + i)
     t.synchronize()
     if world > 1:   # the path's one exchange step: reduce the sum buffers onto rank 0, scale, tonemap
-        mean = ptdist.reduce_accumulation(acc, a.steps * world, dst=0)
+        mean = ptdist.reduce_accumulation(acc if a.backend == "nccl" else acc.cpu(), a.steps * world, dst=0)
         if rank == 0:
+            mean = mean.to(dev)
+            torch.cuda.synchronize()        # torch's stream produced `mean`; the tracer reads it on its own stream
             t.tonemap(mean.data_ptr(), 1.0, W * H, ldr.data_ptr())
     barrier()
     dt = time.perf_counter() - t0
@@ -152,8 +160,9 @@ def main():
 
     cnt = t.counters()
     prof = t.level_profile()
-    rays = torch.tensor([float(cnt.rays)], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    cdev = dev if a.backend == "nccl" else torch.device("cpu")
+    rays = torch.tensor([float(cnt.rays)], dtype=torch.float64, device=cdev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
