@@ -338,7 +338,7 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
     if (!W || !H) return fail(t, MIPT_E_INVALID, "empty viewport");
     if ((uint64_t)W * H >= (1ull << 31)) return fail(t, MIPT_E_LIMIT, "viewport too large");
     if (D > 30) return fail(t, MIPT_E_LIMIT, "maxDepth > 30 (node ids are 32-bit)");
-    if (t->rngMode == MIPT_RNG_DFS) return fail(t, MIPT_E_INVALID, "rng_mode dfs is not available in this build");
+    if (t->rngMode == MIPT_RNG_DFS && D > 16) return fail(t, MIPT_E_LIMIT, "rng_mode dfs supports maxDepth <= 16");
     if (frame_stride == 0) frame_stride = 1;
     const uint32_t npix = W * H;
 
@@ -357,7 +357,9 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
     const int persistentBlocks = t->numCU * (int)t->blocksPerCU;
     uint32_t tile = npix;
     uint32_t wcap = 0;
-    if (t->integrator == 0) {
+    if (t->rngMode == MIPT_RNG_DFS) {
+        // depth-first integrator: no queues
+    } else if (t->integrator == 0) {
         // persistent wave stacks: 256 entries per recursion level per wave (see k_wavestack), independent of the viewport
         wcap = 256u * std::max<uint32_t>(D, 1u) + 256u;
         const size_t need = (size_t)persistentBlocks * 4 * wcap;
@@ -394,7 +396,15 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
         LevelArgs A;
         A.S = sc->dev; A.F = make_frame(*st, frame);
         A.sample = t->sample; A.pixelRays = t->countPixelRays ? t->pixelRays : nullptr; A.stats = t->stats;
-        if (t->integrator == 0 && D >= 1) {
+        if (t->rngMode == MIPT_RNG_DFS) {
+            DfsArgs DA;
+            DA.S = sc->dev; DA.F = A.F; DA.sample = A.sample; DA.pixelRays = A.pixelRays; DA.stats = t->stats; DA.pix0 = 0; DA.npix = npix;
+            mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
+            if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, t->stream)); }
+            launch_dfs(DA, 0, t->stream);
+            if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, t->stream)); t->levelPending.push_back(le); }
+            t->launches++;
+        } else if (t->integrator == 0 && D >= 1) {
             HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), t->stream));
             StackArgs SA;
             SA.S = sc->dev; SA.F = A.F; SA.stack = t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes; SA.pixCounter = t->counts;

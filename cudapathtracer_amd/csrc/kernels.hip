@@ -613,6 +613,115 @@ void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
 }
 
 // =================================================================================================================
+// Depth-first integrator (rng_mode = dfs): the reference's evaluation order, bit for bit.
+//
+// One lane = one pixel-sample, like the reference's megakernel, with LaunchRayRecur's recursion
+// (CUDATracerProg.cu:426-541) unrolled into an explicit per-lane frame stack.  The single LCG of the sample is
+// consumed in the reference's depth-first order (GGX draws, the whole specular subtree, then the diffuse draws), and
+// radiance is combined bottom-up with the reference's expressions, so the sample equals the oracle's DFS mode exactly.
+// This is the fidelity path (divergent, scratch-heavy); the wave-stack integrator is the fast one.
+// =================================================================================================================
+constexpr int kDfsMaxDepth = 16;
+struct DfsFrame {
+    v3 P, N, d, R, color;
+    float rr, rt, n1, n2;
+    uint32_t mesh; int ttl; int stage;
+};
+
+__global__ void __launch_bounds__(kBlock) k_dfs(DfsArgs A) {
+    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= A.npix) return;
+    const uint32_t pix = A.pix0 + idx;
+    DfsFrame fr[kDfsMaxDepth];
+    v3 o, d; uint32_t s0;
+    Lcg rng; rng.state = tea16(pix, A.F.frameID);
+    {   // primary ray: same draws as gen_primary, but the generator keeps running afterwards
+        uint32_t i = pix % A.F.W, j = pix / A.F.W;
+        float offx = rng.NextFloat() * A.F.pixelSize;
+        float offy = rng.NextFloat() * A.F.pixelSize;
+        float u = ((float)(int)i * A.F.pixelSize + A.F.originX + offx);
+        float v = ((float)(int)j * A.F.pixelSize + A.F.originY + offy);
+        v3 dir = mk3(A.F.front[0], A.F.front[1], A.F.front[2]) + mk3(A.F.right[0], A.F.right[1], A.F.right[2]) * u + mk3(A.F.up[0], A.F.up[1], A.F.up[2]) * v;
+        d = normalize3(dir);
+        o = mk3(A.F.camPos[0], A.F.camPos[1], A.F.camPos[2]);
+        s0 = 0; (void)s0;
+    }
+    int depth = 0, ttl = (int)A.F.maxDepth;
+    uint32_t traced = 0;
+    v3 ret = mk3(0, 0, 0);
+    bool entering = true;
+    while (true) {
+        if (entering) {
+            // ---- LaunchRayRecur entry (:428-531)
+            if (ttl <= 0) { ret = mk3(0, 0, 0); entering = false; continue; }
+            traced++;
+            HitRec h = traverse(A.S.nodes, A.S.refs, o, d, ldsStack + threadIdx.x);
+            if (h.ref < 0) { ret = on_miss(A.S, d); entering = false; continue; }
+            Surface sf = surface_at(A.S, o, d, h);
+            Material mat = load_material(A.S, sf.mesh);
+            v3 mN = ggx_rand_dir_inside_cone(rng, sf.N, mat.roughness);
+            v3 R = reflect3(d, mN);
+            float n1 = 1.f, n2 = mat.n; n2 += FLT_EPSILON;
+            if (!h.front) { float t = n1; n1 = n2; n2 = t; }
+            float r0 = (n1 - n2) / (n1 + n2); r0 *= r0;
+            float rr = (1 - dot3(-d, mN));
+            rr = pow5_mul(rr);
+            rr = r0 + (1 - r0) * rr;
+            rr = saturatef(rr);
+            rr = mat.metallic * 1.f + (1 - mat.metallic) * rr;
+            DfsFrame& f = fr[depth];
+            f.P = sf.P; f.N = sf.N; f.d = d; f.R = R; f.rr = rr; f.rt = 1 - rr; f.n1 = n1; f.n2 = n2; f.mesh = sf.mesh; f.ttl = ttl; f.stage = 1;
+            o = sf.P + sf.N * 1e-6f; d = R;
+            ttl -= 1; depth += 1;
+            continue;
+        }
+        // ---- a call has returned `ret`
+        if (depth == 0) break;
+        depth -= 1;
+        DfsFrame& f = fr[depth];
+        Material mat = load_material(A.S, f.mesh);
+        if (f.stage == 1) {
+            v3 c = mk3(__builtin_fmaxf(ret.x, 0.f), __builtin_fmaxf(ret.y, 0.f), __builtin_fmaxf(ret.z, 0.f));   // :459
+            v3 absorb = mat.metallic * mat.color + (1 - mat.metallic) * mk3(1.f, 1.f, 1.f);
+            f.color = absorb * c * f.rr;
+            if (mat.opacity < 1.f) {
+                v3 frontv = (f.d + f.R) / 2.0f;
+                v3 down = f.d - frontv;
+                float down_len = length3(down);
+                down = down_len < 1e-10f ? mk3(1, 0, 0) : (down / down_len);
+                v3 front_refr = frontv * (f.n1 / f.n2);
+                float frl = length3(front_refr);
+                if (frl > 1) frl = 1;
+                float drl = __builtin_sqrtf(1 - frl * frl);
+                d = normalize3(front_refr + down * drl);
+                o = f.P - f.N * 1e-6f;
+            } else {
+                d = rand_dir_inside_cone(rng, f.N, 0.49f);
+                o = f.P + f.N * 1e-6f;
+            }
+            f.stage = 2;
+            ttl = f.ttl - 1; depth += 1;
+            entering = true;
+        } else {
+            v3 color = f.color + mat.color * ret * f.rt * ((mat.opacity == 1.f) ? 1.f : (1 - mat.opacity));   // :526
+            color = color + mat.emissive * mat.emissiveStrength;                                                // :528
+            ret = color;
+        }
+    }
+    float* p = A.sample + (size_t)pix * 4;
+    p[0] = ret.x; p[1] = ret.y; p[2] = ret.z;
+    if (A.pixelRays) A.pixelRays[pix] = traced;
+    for (int sh = 32; sh > 0; sh >>= 1) traced += __shfl_down(traced, sh);
+    if ((threadIdx.x & 63) == 0 && traced) atomicAdd(A.stats, (unsigned long long)traced);
+}
+void launch_dfs(const DfsArgs& a, int blocks, hipStream_t s) {
+    (void)blocks;
+    if (!a.npix) return;
+    hipLaunchKernelGGL(k_dfs, dim3((a.npix + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+}
+
+// =================================================================================================================
 // Accumulate + tonemap (tail of GenRay, CUDATracerProg.cu:892-919)
 // =================================================================================================================
 MIPT_DEV unsigned char tonemap1(float x) {

@@ -301,3 +301,36 @@ def test_device_buffer_layer(tracer, ptlib):
     assert lib.mipt_buffer_async_gpu_push(b2) == 0 and lib.mipt_buffer_head(b2) == 3
     tracer.synchronize()
     lib.mipt_buffer_destroy(b2)
+
+
+@pytest.mark.parametrize("name,w,h,depth", [("cornell", 128, 80, 4), ("default", 96, 96, 8), ("cornell", 64, 48, 8)])
+def test_dfs_order_integrator_is_bit_identical_to_the_oracle(tracer, ptlib, oracle, name, w, h, depth):
+    """rng_mode = dfs: the reference's single LCG stream per pixel-sample in its depth-first order and its bottom-up
+    radiance arithmetic.  No atomics are involved, so the sample, the accumulation buffer and the LDR bytes must equal
+    the oracle's DFS mode (same flat BVH, portable math) bit for bit."""
+    which, cam_kw, env, _, _ = MG.CONFIGS[name]
+    data = MG.scene_data(name)
+    sc = ptlib.Scene(tracer, data)
+    o = oracle.Scene(data)
+    o.set_flat_bvh(*sc.bvh())
+    s = ptlib.make_settings(ptlib.make_camera(**cam_kw), w, h, depth)
+    acc, ldr = dev_buffers(tracer, w, h)
+    tracer.set_option("rng_mode", ptlib.RNG_DFS)
+    tracer.set_option("count_pixel_rays", 1)
+    try:
+        exp_acc = np.zeros((h, w, 4), np.float32)
+        for frame in (0, 1, 2):
+            s.frameID = frame
+            tracer.trace(sc, s, acc, ldr)
+            rgb, rays = tracer.last_sample(w * h, rays=True)
+            r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_DFS, oracle.MATH_DET, frame, 1, acc=exp_acc, nthreads=16)
+            assert np.array_equal(rays.reshape(h, w), r["rays"])
+            assert np.array_equal(rgb.reshape(h, w, 3).view(np.uint32), r["sample"].view(np.uint32))
+            assert np.array_equal(tracer.download(acc, (h, w, 4), np.float32).view(np.uint32), r["acc"].view(np.uint32))
+            assert np.array_equal(tracer.download(ldr, (h, w, 4), np.uint8), r["ldr"])
+        with pytest.raises(ptlib.MiptError):
+            tracer.render(sc, ptlib.make_settings(ptlib.make_camera(**cam_kw), w, h, 17), 0, 1, acc)
+    finally:
+        tracer.set_option("rng_mode", ptlib.RNG_NODE)
+        tracer.set_option("count_pixel_rays", 0)
+        tracer.free(acc), tracer.free(ldr)
