@@ -186,13 +186,23 @@ def main():
             n_node, n_tri, miss = cpu["n_node"], cpu["n_tri"], cpu["miss_frac"]
             if a.integrator == 0:
                 n_node, n_tri, miss = cpu["n_node_all"], cpu["n_tri_all"], cpu["miss_all"]
+        traffic = a.traffic_gb
+        if traffic is None and a.integrator == 0 and (W, H) == (1920, 1080):
+            # HBM bytes per launch from the committed PMC passes of this same command (scripts/pmc_passes.sh;
+            # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, plus WRITE_SIZE)
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")))
+                traffic = round(pj[a.workload]["hbm_gb_per_launch"], 2)
+            except Exception:
+                traffic = None
         roof = None
         if n_node is not None and sec_ms > 0:
             # B_ray = 64*N_node + 48*N_tri + 64 (+12 per env-map miss); units per launch = rays of that launch
             b_ray = 64.0 * n_node + 48.0 * n_tri + 64.0 + (12.0 * miss if data.env is not None else 0.0)
             achieved = sec_rays * b_ray / (sec_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": a.traffic_gb,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
+                    "algorithmic_gb_per_launch": round(sec_rays / max(sec_launches, 1) * b_ray / 1e9, 2),
                     "kernel": kernel_name, "bytes_per_ray": round(b_ray, 1), "n_node_per_ray": round(n_node, 3),
                     "n_tri_per_ray": round(n_tri, 3), "rays_per_launch": round(sec_rays / max(sec_launches, 1), 1),
                     "avg_launch_ms": round(sec_ms / max(sec_launches, 1), 4), "launches": int(sec_launches),
