@@ -51,7 +51,7 @@ class MeshDesc(C.Structure):
 class SceneDesc(C.Structure):
     _fields_ = [("meshes", C.POINTER(MeshDesc)), ("meshCnt", C.c_uint32), ("sky", SkyLight),
                 ("envMap", C.c_void_p), ("envW", C.c_uint32), ("envH", C.c_uint32),
-                ("bvhBuilder", C.c_uint32), ("maxLeafSize", C.c_uint32), ("splitAlpha", C.c_float)]
+                ("bvhBuilder", C.c_uint32), ("maxLeafSize", C.c_uint32), ("splitAlpha", C.c_float), ("sahTriCost", C.c_float)]
 
 
 class Counters(C.Structure):
@@ -246,13 +246,13 @@ DEFAULT_CAMERA = dict(pos=(-1.0, 1.0, 0.0), azimuth=0.0, zenith=float(np.float32
 
 # ---- handles -----------------------------------------------------------------------------------------------------
 class Scene:
-    def __init__(self, tracer, data, builder=BVH_SBVH, max_leaf=0, split_alpha=0.0):
+    def __init__(self, tracer, data, builder=BVH_SBVH, max_leaf=0, split_alpha=0.0, tri_cost=0.0):
         """tracer may be None: host-only scene (BVH build + get_bvh), usable without a GPU."""
         self.h = None
         self.tracer = tracer
         self.data = data
         desc, keep = data.fill_desc(SceneDesc, MeshDesc)
-        desc.bvhBuilder, desc.maxLeafSize, desc.splitAlpha = builder, max_leaf, split_alpha
+        desc.bvhBuilder, desc.maxLeafSize, desc.splitAlpha, desc.sahTriCost = builder, max_leaf, split_alpha, tri_cost
         h = _vp()
         rc = lib.mipt_scene_create(tracer.h if tracer else None, C.byref(desc), C.byref(h))
         if rc != 0:

@@ -259,6 +259,7 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
     if (bp.builder != MIPT_BVH_SBVH && bp.builder != MIPT_BVH_MEDIAN) return fail(t, MIPT_E_INVALID, "unknown bvhBuilder");
     if (d->maxLeafSize) bp.maxLeafSize = d->maxLeafSize;
     if (d->splitAlpha > 0.f) bp.splitAlpha = d->splitAlpha;
+    if (d->sahTriCost > 0.f) bp.triCost = d->sahTriCost;
     BvhOut bo;
     std::string berr = build_bvh(tris, bp, bo);
     if (!berr.empty()) return fail(t, MIPT_E_LIMIT, "BVH build: " + berr);

@@ -18,9 +18,11 @@ struct BvhParams {
     uint32_t builder = 0;        // 0 SBVH, 1 median
     uint32_t maxLeafSize = 4;    // <= 15
     float    splitAlpha = 1.0e-5f;   // SplitBVHBuilder.hpp:67
-    // SAH constants: the reference's `Platform` is undeclared; pinned here as in NVIDIA's default Platform.
+    // SAH constants: the reference's `Platform` is undeclared.  NVIDIA's default Platform uses 1 / 1; on
+    // gfx950 a Moller-Trumbore test issues ~75 VALU instructions against ~50 for a two-box node visit, and the
+    // measured optimum (profiles/r1/exp_sah_tricost_leafsize.log) is 1 / 1.5.
     float    nodeCost = 1.0f;    // getNodeCost(n) = nodeCost * n
-    float    triCost = 1.0f;     // getTriangleCost(n) = triCost * n
+    float    triCost = 1.5f;     // getTriangleCost(n) = triCost * n
     uint32_t minLeafSize = 1;
 };
 

@@ -50,6 +50,7 @@ typedef struct {
     uint32_t bvhBuilder;                                /* MIPT_BVH_* */
     uint32_t maxLeafSize;                               /* 0 = default (4); at most 15 */
     float    splitAlpha;                                /* SBVH spatial-split threshold; 0 = reference default 1e-5 */
+    float    sahTriCost;                                /* SAH cost of one triangle test relative to a node visit; 0 = default (1.5) */
 } mipt_scene_desc;
 
 typedef struct mipt_tracer mipt_tracer;   /* replaces CUDATracerProg            CUDATracerProg.cu:925-935 */
