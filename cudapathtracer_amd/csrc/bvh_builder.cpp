@@ -12,12 +12,21 @@
 // Differences from the spec, all build-side: one tree over all meshes (no per-mesh loop); leaves hold at most 15
 // references; a subtree whose depth budget runs out falls back to balanced median splits so that the device's
 // 64-entry traversal stack can never overflow.
+//
+// Parallel build: a node with >= kTaskMin references hands its right subtree to a child Builder (own reference
+// stack, own output) that may run on another thread; the child's output is spliced behind the left subtree's with its
+// node / reference indices rebased.  Whether a subtree is built by a child depends only on its reference count, and
+// the big sorts are chunk-sort + merge under a strict total order, so the tree is identical for every thread count.
 #include "bvh_builder.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <future>
 #include <limits>
+#include <thread>
 
 namespace mipt {
 namespace {
@@ -44,9 +53,42 @@ struct Spec { int n = 0; Box b; };
 
 int ceil_log2(uint32_t n) { int l = 0; while ((1u << l) < n && l < 31) l++; return l; }
 
+constexpr int kTaskMin = 1 << 15;        // references: subtrees at least this big are built by a child Builder
+constexpr size_t kSortChunk = 1 << 16;   // smallest range worth sorting on another thread
+
+// extra worker threads that may still be started (the calling thread is not counted)
+std::atomic<int> g_spare{0};
+bool take_thread() {
+    int v = g_spare.load(std::memory_order_relaxed);
+    while (v > 0) if (g_spare.compare_exchange_weak(v, v - 1)) return true;
+    return false;
+}
+void give_thread() { g_spare.fetch_add(1); }
+
+template <class It, class Cmp>
+void psort(It b, It e, Cmp c) {
+    const size_t n = (size_t)(e - b);
+    if (n < 2 * kSortChunk || !take_thread()) { std::sort(b, e, c); return; }
+    It m = b + n / 2;
+    auto f = std::async(std::launch::async, [=] { psort(b, m, c); give_thread(); });
+    psort(m, e, c);
+    f.get();
+    std::inplace_merge(b, m, e, c);
+}
+
 class Builder {
 public:
     Builder(const std::vector<TriPos>& t, const BvhParams& p, BvhOut& o) : T(t), P(p), O(o) {}
+
+    // a subtree of a parent Builder: `refs` are its references, the result (root reference, local indices) is
+    // returned and the nodes / references land in this Builder's own output
+    uint32_t run_subtree(std::vector<Ref>&& refs, const Spec& s, int level, float minOv) {
+        stk = std::move(refs);
+        minOverlap = minOv;
+        rightB.resize(std::max<size_t>(stk.size(), kSpatialBins));
+        O.nodes.clear(); O.refTri.clear(); O.maxDepth = 0;
+        return build(s, level);
+    }
 
     std::string run() {
         const size_t nt = T.size();
@@ -109,7 +151,7 @@ private:
         return make_leaf_ref(first, (uint32_t)s.n);
     }
     void sort_tail(int n, int dim) {
-        std::sort(stk.end() - n, stk.end(), [dim](const Ref& a, const Ref& b) {
+        psort(stk.end() - n, stk.end(), [dim](const Ref& a, const Ref& b) {
             float ca = a.b.mn[dim] + a.b.mx[dim], cb = b.b.mn[dim] + b.b.mx[dim];
             if (ca == cb) return a.tri < b.tri;
             return ca < cb;
@@ -172,10 +214,46 @@ private:
 
         uint32_t self = new_node();
         O.maxDepth = std::max<uint32_t>(O.maxDepth, (uint32_t)level);
-        uint32_t rr = build(R, level + 1);   // right references are on top of the stack
-        uint32_t lr = build(L, level + 1);
+        uint32_t rr, lr;
+        if (s.n >= kTaskMin && R.n > 0) {
+            // right subtree -> child Builder (possibly on another thread), left subtree here, then splice
+            std::vector<Ref> rrefs(stk.end() - R.n, stk.end());
+            stk.resize(stk.size() - R.n);
+            BvhOut co;
+            Builder child(T, P, co);
+            uint32_t cr = 0;
+            auto job = [&] { cr = child.run_subtree(std::move(rrefs), R, level + 1, minOverlap); };
+            if (take_thread()) {
+                auto f = std::async(std::launch::async, [&] { job(); give_thread(); });
+                lr = build(L, level + 1);
+                f.get();
+            } else {
+                lr = build(L, level + 1);
+                job();
+            }
+            rr = splice(co, cr);
+        } else {
+            rr = build(R, level + 1);   // right references are on top of the stack
+            lr = build(L, level + 1);
+        }
         set_child(self, 0, lr, L.b); set_child(self, 1, rr, R.b);
         return self;
+    }
+
+    // append a child Builder's output, rebasing its node and reference indices; returns the rebased root reference
+    uint32_t splice(const BvhOut& co, uint32_t root) {
+        const uint32_t nodeOff = (uint32_t)(O.nodes.size() / 16), refOff = (uint32_t)O.refTri.size();
+        auto fix = [&](uint32_t r) { return (r & kLeafFlag) ? (r & 0xF8000000u) | ((r & 0x07FFFFFFu) + refOff) : r + nodeOff; };
+        const size_t base = O.nodes.size();
+        O.nodes.insert(O.nodes.end(), co.nodes.begin(), co.nodes.end());
+        for (size_t i = base; i < O.nodes.size(); i += 16) {
+            uint32_t r[2]; memcpy(r, &O.nodes[i + 12], 8);
+            r[0] = fix(r[0]); r[1] = fix(r[1]);
+            memcpy(&O.nodes[i + 12], r, 8);
+        }
+        O.refTri.insert(O.refTri.end(), co.refTri.begin(), co.refTri.end());
+        O.maxDepth = std::max(O.maxDepth, co.maxDepth);
+        return fix(root);
     }
 
     ObjSplit find_object_split(const Spec& s, float nodeSAH) {
@@ -297,6 +375,11 @@ private:
 }  // namespace
 
 std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOut& out) {
+    // worker threads: $MIPT_BUILD_THREADS, else the hardware's, at most 16 (a GPU box's CPU share)
+    int threads = (int)std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("MIPT_BUILD_THREADS")) threads = std::atoi(e);
+    threads = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+    g_spare.store(threads - 1);
     Builder b(tris, p, out);
     return b.run();
 }

@@ -150,3 +150,27 @@ def test_grid_mesh_and_synthetic_sky(ptlib):
     assert sky.shape == (128, 256, 3) and sky.min() >= 0 and sky.max() == 5.0e4
     assert np.array_equal(sky, ptlib.synthetic_sky(256, 128, 0x5EED))
     assert sky[:64].mean() > sky[64:].mean()               # bright sky above, dark ground below
+
+
+def test_parallel_build_is_thread_count_independent(ptlib, oracle, monkeypatch):
+    # 131 k triangles: above the builder's task threshold, so right subtrees are built by child builders and spliced
+    v, i = ptlib.grid_mesh(256, 8.0, 1.0, 1)
+    data = ptlib.SceneData([(v, i, ptlib.make_material())], ptlib.SkyLight())
+    out = []
+    for threads in ("1", "2", "7"):
+        monkeypatch.setenv("MIPT_BUILD_THREADS", threads)
+        nodes, refs = ptlib.Scene(None, data).bvh()
+        out.append((nodes.copy(), refs.copy()))
+    for nodes, refs in out[1:]:
+        assert np.array_equal(nodes.view(np.uint32), out[0][0].view(np.uint32)) and np.array_equal(refs, out[0][1])
+    nodes, refs = out[0]
+    o = oracle.Scene(data)
+    o.set_flat_bvh(nodes, refs)
+    assert o.check_flat_bvh() == (0, "")
+    og, dg = random_rays(20000, 33, -6, 6)
+    og[:, 1] = 2 + np.abs(og[:, 1]) * 0.3
+    dg[:, 1] = -np.abs(dg[:, 1])
+    f, _ = o.trace_rays(oracle.ISECT_FLAT, og, dg)
+    b, _ = o.trace_rays(oracle.ISECT_BRUTE, og, dg)
+    assert (f["tri"] >= 0).sum() > 5000
+    assert ((f["tri"] != b["tri"]) | (f["t"] != b["t"])).sum() <= 10
