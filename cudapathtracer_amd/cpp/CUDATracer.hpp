@@ -3,6 +3,7 @@
 // argument meaning, so a RendererWindow-style caller compiles unchanged.  Errors surface as std::runtime_error with
 // libmipt's message where the reference calls __debugbreak() (CUDACommon.h:34-54).
 #pragma once
+#include <cstdlib>
 #include <memory>
 #include <vector>
 
@@ -23,7 +24,8 @@ static_assert(sizeof(PathTraceSettings) == sizeof(mipt_settings), "PathTraceSett
 // Scene upload: one flat BVH + triangle stream for the whole scene (CUDAScene, CUDATracer.hpp:82-227)
 class CUDAScene {
 public:
-    explicit CUDAScene(const Scene& scn, unsigned bvhBuilder = MIPT_BVH_SBVH) {
+    // bvhCachePath: optional BVH cache file (mipt_scene_desc::bvhCachePath); $MIPT_BVH_CACHE is used when it is null
+    explicit CUDAScene(const Scene& scn, unsigned bvhBuilder = MIPT_BVH_SBVH, const char* bvhCachePath = nullptr) {
         std::vector<mipt_mesh_desc> meshes(scn.objects.size());
         for (size_t i = 0; i < scn.objects.size(); i++) {
             const Mesh& m = scn.objects[i];
@@ -39,6 +41,7 @@ public:
         std::memcpy(&d.sky, &scn.skyLight, sizeof(mipt_skylight));
         if (!scn.envMap.empty()) { d.envMap = scn.envMap.data(); d.envW = scn.envMapDim.x; d.envH = scn.envMapDim.y; }
         d.bvhBuilder = bvhBuilder;
+        d.bvhCachePath = bvhCachePath ? bvhCachePath : std::getenv("MIPT_BVH_CACHE");
         detail::Check(mipt_scene_create(detail::DefaultTracer(), &d, &_s), "mipt_scene_create");
         _meshCnt = d.meshCnt;
     }
@@ -49,6 +52,7 @@ public:
     const void* GetGPUData() { return _s; }
     mipt_scene* handle() { return _s; }
     unsigned meshCnt() const { return _meshCnt; }
+    bool BvhWasCached() const { return mipt_scene_bvh_was_cached(_s) != 0; }
 private:
     mipt_scene* _s = nullptr;
     unsigned _meshCnt = 0;

@@ -2,6 +2,7 @@
 // Common/GLFWWindow.cpp:128-147): same members and call sequence (resize -> loop { Trace; bitmap->cpu_data();
 // frameID++ }), no GLFW/OpenGL.  DrawBitmap keeps the last frame and can write it as a PPM instead of blitting it.
 #pragma once
+#include <cmath>
 #include <cstdio>
 #include <memory>
 #include <string>
@@ -20,6 +21,7 @@ protected:
     CUDATracer::PathTracer* renderer;
     std::vector<std::uint8_t> lastFrame;
     unsigned width, height;
+    std::string previewPrefix; unsigned previewEvery = 0;
 
     void UpdateCam(CUDATracer::Camera& cam) { CUDATracer::Scenes::UpdateCam(camParam, cam); }
 
@@ -51,13 +53,41 @@ public:
         settings.viewportHeight = newSize.y; settings.viewportWidth = newSize.x;
         ResetFrameID();
     }
-    virtual void Update() { UpdateCam(renderSettings->GetMutable<0>().cam); }
+    virtual void Update() { HandleKeyInput(); UpdateCam(renderSettings->GetMutable<0>().cam); }
+
+    // Input without a window: the reference polls GLFW keys / mouse (RendererWindow.hpp:150-183); here the same state is
+    // injected by the caller.  Same steps (0.1 per frame along front/right, 1/400 rad per pixel) and the same rule:
+    // any camera change restarts the accumulation (ResetFrameID).
+    struct KeyState { bool w = false, s = false, a = false, d = false; } keys;
+    bool mouseLeftDown = false;
+    CUDATracer::Math::vec2f lastMousePos{ 0.f, 0.f };
+    void HandleKeyInput() {
+        int fwd = (keys.w ? 1 : 0) - (keys.s ? 1 : 0), right = (keys.d ? 1 : 0) - (keys.a ? 1 : 0);
+        if (fwd != 0 || right != 0) {
+            auto& cam = renderSettings->GetMutable<0>().cam;
+            camParam.pos += cam.front * (float)(fwd * 0.1);
+            camParam.pos += cam.right * (float)(right * 0.1);
+            ResetFrameID();
+        }
+    }
+    virtual void mouseMotion(double px, double py) {
+        double dx = px - lastMousePos.x, dy = py - lastMousePos.y;
+        lastMousePos = { (float)px, (float)py };
+        if (std::abs(dx) < 1e-3 && std::abs(dy) < 1e-3) return;
+        if (mouseLeftDown) { camParam.azimuth += (float)(dx / 400); camParam.zenith += (float)(dy / 400); ResetFrameID(); }
+    }
+
+    // progressive preview: write "<prefix>_<frames>.ppm" after every `every` accumulated frames (0 = off)
+    void SetPreview(const std::string& prefix, unsigned every) { previewPrefix = prefix; previewEvery = every; }
+    bool SceneBvhWasCached() { return renderScene.BvhWasCached(); }
 
     virtual void render() {
         renderer->Trace(renderScene, *renderSettings, (float*)accBuffer->mutable_gpu_data(), (char*)bitmap->mutable_gpu_data());
         auto tbuffer = (const std::uint8_t*)bitmap->cpu_data();       // blocking readback, observes the frame
         renderSettings->GetMutable<0>().frameID++;                    // the CALLER advances the sample index
         DrawBitmap(bitmapSize.x, bitmapSize.y, tbuffer);
+        const unsigned done = renderSettings->Get<0>().frameID;
+        if (previewEvery && done % previewEvery == 0) WritePPM(previewPrefix + "_" + std::to_string(done) + ".ppm");
     }
     virtual void DrawBitmap(int w, int h, const std::uint8_t* rgba) { lastFrame.assign(rgba, rgba + (size_t)w * h * 4); }
 

@@ -56,6 +56,7 @@ struct mipt_scene {
     void* dNodes = nullptr; void* dRefs = nullptr; void* dShade = nullptr; void* dMats = nullptr; void* dEnv = nullptr;
     std::vector<float> hNodes, hRefs;    // host copies for mipt_scene_get_bvh
     uint32_t nTris = 0;
+    bool bvhFromCache = false;
 };
 
 struct mipt_buffer {
@@ -116,6 +117,51 @@ FrameDev make_frame(const mipt_settings& s, uint32_t frameID) {
 }
 
 inline float hdot(const float* a, const float* b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+
+// ---- BVH cache file: header, nodes (16 floats each), refTri (uint32 each) --------------------------------------
+struct BvhCacheHeader {
+    char magic[8];              // "MIPTBVH1"
+    uint64_t key;               // hash of the triangle positions and the build parameters
+    uint32_t nTris, nNodes, nRefs, reserved;
+};
+uint64_t bvh_cache_key(const std::vector<TriPos>& tris, const BvhParams& bp) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&](uint64_t w) { h = (h ^ w) * 0x100000001b3ull; h ^= h >> 29; };
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(tris.data());
+    const size_t n = tris.size() * 9;
+    size_t i = 0;
+    for (; i + 1 < n; i += 2) mix((uint64_t)w[i] | ((uint64_t)w[i + 1] << 32));
+    if (i < n) mix(w[i]);
+    uint32_t a, c; memcpy(&a, &bp.splitAlpha, 4); memcpy(&c, &bp.triCost, 4);
+    mix(bp.builder); mix(bp.maxLeafSize); mix(a); mix(c); mix(tris.size());
+    return h;
+}
+bool load_bvh_cache(const char* path, uint64_t key, uint32_t nTris, BvhOut& bo) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    BvhCacheHeader h;
+    bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "MIPTBVH1", 8) && h.key == key && h.nTris == nTris &&
+              h.nNodes > 0 && h.nNodes < (1u << 27) && h.nRefs < (1u << 27);
+    if (ok) {
+        bo.nodes.resize((size_t)h.nNodes * 16); bo.refTri.resize(h.nRefs);
+        ok = fread(bo.nodes.data(), 64, h.nNodes, f) == h.nNodes && (h.nRefs == 0 || fread(bo.refTri.data(), 4, h.nRefs, f) == h.nRefs);
+    }
+    fclose(f);
+    return ok && validate_bvh(bo, nTris).empty();
+}
+bool save_bvh_cache(const char* path, uint64_t key, uint32_t nTris, const BvhOut& bo) {
+    std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    BvhCacheHeader h; memcpy(h.magic, "MIPTBVH1", 8); h.key = key; h.nTris = nTris;
+    h.nNodes = (uint32_t)(bo.nodes.size() / 16); h.nRefs = (uint32_t)bo.refTri.size(); h.reserved = 0;
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(bo.nodes.data(), 64, h.nNodes, f) == h.nNodes &&
+              (h.nRefs == 0 || fwrite(bo.refTri.data(), 4, h.nRefs, f) == h.nRefs);
+    ok = (fclose(f) == 0) && ok;
+    if (ok) ok = rename(tmp.c_str(), path) == 0;
+    if (!ok) remove(tmp.c_str());
+    return ok;
+}
 
 }  // namespace
 
@@ -261,11 +307,19 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
     if (d->splitAlpha > 0.f) bp.splitAlpha = d->splitAlpha;
     if (d->sahTriCost > 0.f) bp.triCost = d->sahTriCost;
     BvhOut bo;
-    std::string berr = build_bvh(tris, bp, bo);
-    if (!berr.empty()) return fail(t, MIPT_E_LIMIT, "BVH build: " + berr);
+    const bool useCache = d->bvhCachePath && d->bvhCachePath[0];
+    const uint64_t cacheKey = useCache ? bvh_cache_key(tris, bp) : 0;
+    const bool cached = useCache && load_bvh_cache(d->bvhCachePath, cacheKey, (uint32_t)tris.size(), bo);
+    if (!cached) {
+        bo = BvhOut();
+        std::string berr = build_bvh(tris, bp, bo);
+        if (!berr.empty()) return fail(t, MIPT_E_LIMIT, "BVH build: " + berr);
+        if (useCache && !save_bvh_cache(d->bvhCachePath, cacheKey, (uint32_t)tris.size(), bo))
+            return fail(t, MIPT_E_INVALID, std::string("cannot write BVH cache ") + d->bvhCachePath);
+    }
 
     mipt_scene* s = new mipt_scene();
-    s->t = t; s->nTris = (uint32_t)tris.size();
+    s->t = t; s->nTris = (uint32_t)tris.size(); s->bvhFromCache = cached;
     s->hNodes = std::move(bo.nodes);
     s->hRefs.resize(bo.refTri.size() * 12);
     for (size_t r = 0; r < bo.refTri.size(); r++) {
@@ -326,6 +380,7 @@ int mipt_scene_get_bvh(const mipt_scene* s, float* nodes, uint32_t* n_nodes, flo
     return MIPT_OK;
 }
 uint32_t mipt_scene_triangle_count(const mipt_scene* s) { return s ? s->nTris : 0; }
+int mipt_scene_bvh_was_cached(const mipt_scene* s) { return s && s->bvhFromCache ? 1 : 0; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // The hot path

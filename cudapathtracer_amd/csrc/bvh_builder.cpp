@@ -384,4 +384,39 @@ std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOu
     return b.run();
 }
 
+std::string validate_bvh(BvhOut& out, uint32_t nTris) {
+    const size_t nNodes = out.nodes.size() / 16, nRefs = out.refTri.size();
+    if (out.nodes.size() % 16 || nNodes == 0) return "node array is empty or not a multiple of 16 floats";
+    if (nNodes >= kLeafFlag || nRefs >= (1u << 27)) return "too many nodes or references";
+    for (uint32_t t : out.refTri) if (t >= nTris) return "reference to a triangle out of range";
+    std::vector<uint8_t> seenNode(nNodes, 0), seenTri(nTris, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> todo{ {0u, 0u} };    // (node, level)
+    seenNode[0] = 1;
+    size_t visited = 0; uint32_t deepest = 0;
+    while (!todo.empty()) {
+        auto [n, level] = todo.back(); todo.pop_back();
+        visited++;
+        if (level >= kMaxBvhDepth) return "BVH deeper than the device traversal stack";
+        deepest = std::max(deepest, level);
+        uint32_t r[2]; memcpy(r, &out.nodes[(size_t)n * 16 + 12], 8);
+        for (int c = 0; c < 2; c++) {
+            if (r[c] & kLeafFlag) {
+                const uint32_t cnt = (r[c] >> 27) & 0xFu, first = r[c] & 0x07FFFFFFu;
+                if ((size_t)first + cnt > nRefs) return "leaf range out of bounds";
+                for (uint32_t i = first; i < first + cnt; i++) seenTri[out.refTri[i]] = 1;
+            } else {
+                if (r[c] >= nNodes) return "child node index out of range";
+                if (seenNode[r[c]]) return "node reached twice (not a tree)";
+                seenNode[r[c]] = 1;
+                todo.push_back({ r[c], level + 1 });
+            }
+        }
+    }
+    if (visited != nNodes) return "unreachable nodes";
+    for (uint32_t t = 0; t < nTris; t++) if (!seenTri[t]) return "a triangle is referenced by no leaf";
+    out.maxDepth = deepest;
+    out.duplicates = (uint32_t)(nRefs - nTris);
+    return "";
+}
+
 }  // namespace mipt

@@ -40,4 +40,9 @@ inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return kLeafFlag
 // returns empty string on success, otherwise an error message
 std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOut& out);
 
+// Structural check of a flat BVH that did not come straight from build_bvh (a cache file): every index in range, the
+// nodes form one tree rooted at node 0 (each node reached exactly once), depth below the device stack, every triangle
+// referenced.  Sets out.maxDepth / out.duplicates.  Returns empty string when the BVH is safe to traverse.
+std::string validate_bvh(BvhOut& out, uint32_t nTris);
+
 }  // namespace mipt

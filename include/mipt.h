@@ -51,6 +51,10 @@ typedef struct {
     uint32_t maxLeafSize;                               /* 0 = default (4); at most 15 */
     float    splitAlpha;                                /* SBVH spatial-split threshold; 0 = reference default 1e-5 */
     float    sahTriCost;                                /* SAH cost of one triangle test relative to a node visit; 0 = default (1.5) */
+    const char* bvhCachePath;                           /* NULL, or a file: if it holds the BVH of exactly these triangles and
+                                                           build parameters it is loaded (structure re-validated) instead of
+                                                           building; otherwise the BVH is built and written there.  No
+                                                           counterpart in the reference (its BVH is rebuilt per run, Types.hpp:292) */
 } mipt_scene_desc;
 
 typedef struct mipt_tracer mipt_tracer;   /* replaces CUDATracerProg            CUDATracerProg.cu:925-935 */
@@ -98,6 +102,7 @@ void mipt_scene_destroy(mipt_scene*);
  * refs = 12 floats each [v0 xyz, triId][e1 xyz, meshId][e2 xyz, 0].  Pass NULL buffers to query the counts. */
 int  mipt_scene_get_bvh(const mipt_scene*, float* nodes, uint32_t* n_nodes, float* refs, uint32_t* n_refs);
 uint32_t mipt_scene_triangle_count(const mipt_scene*);
+int  mipt_scene_bvh_was_cached(const mipt_scene*);          /* 1 if the BVH came from desc.bvhCachePath, 0 if it was built */
 
 /* ---- the hot path: PathTracer::Trace (CUDATracer.hpp:352-358; CUDATracerProg.cu:937-963) -------------------
  * One sample per pixel for sample index settings->frameID, folded into acc_dev (w*h*4 floats, running mean with

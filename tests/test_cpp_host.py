@@ -87,3 +87,186 @@ def test_defaultscene_app_runs(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     img = np.frombuffer(open(ppm, "rb").read()[len(b"P6 128 72 255\n"):], np.uint8)
     assert img.max() <= 186 and img.mean() > 5
+
+
+OBJ_TEXT = """# a unit cube as quads with shared corners, no normals, plus one triangle with explicit normals / relative indices
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0 0 1
+v 1 0 1
+v 1 1 1
+v 0 1 1
+vt 0.5 0.25
+vn 0 0 1
+f 1 4 3 2
+f 5 6 7 8
+f 1 2 6 5
+f 2 3 7 6
+f 3 4 8 7
+f 4 1 5 8
+v 2 0 0
+v 3 0 0
+v 2 1 0
+f -3/1/1 -2/1/1 -1//-1
+"""
+
+OBJ_MAIN = r"""
+#include <cstdio>
+#include "ObjLoader.hpp"
+using namespace CUDATracer;
+int main(int argc, char** argv) {
+    try {
+        auto m = LoadOBJ(argv[1]);
+        auto& v = std::get<0>(m); auto& i = std::get<1>(m);
+        std::printf("%zu %zu\n", v.size(), i.size());
+        for (auto& x : v) std::printf("%g %g %g  %.6f %.6f %.6f  %g %g\n", x.position.x, x.position.y, x.position.z, x.normal.x, x.normal.y, x.normal.z, x.uv.x, x.uv.y);
+        for (size_t k = 0; k < i.size(); k += 3) std::printf("t %u %u %u\n", i[k], i[k + 1], i[k + 2]);
+    } catch (const std::exception& e) { std::printf("error: %s\n", e.what()); return 1; }
+    return 0;
+}
+"""
+
+
+def _build_obj_tool(tmp_path):
+    src = tmp_path / "obj_main.cpp"
+    src.write_text(OBJ_MAIN)
+    exe = str(tmp_path / "obj_main")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "cudapathtracer_amd", "cpp"), str(src), "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_obj_loader_parses_polygons_relative_indices_and_smooth_normals(tmp_path):
+    exe = _build_obj_tool(tmp_path)
+    obj = tmp_path / "cube.obj"
+    obj.write_text(OBJ_TEXT)
+    r = subprocess.run([exe, str(obj)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    lines = r.stdout.strip().splitlines()
+    nv, ni = map(int, lines[0].split())
+    assert (nv, ni) == (8 + 3, 12 * 3 + 3)                       # corners share a vertex per position; quads -> 2 triangles
+    verts = np.array([[float(x) for x in l.split()] for l in lines[1:1 + nv]])
+    tris = np.array([[int(x) for x in l.split()[1:]] for l in lines[1 + nv:]])
+    assert tris.shape == (13, 3) and tris.max() == nv - 1
+    assert {tuple(v) for v in verts[:8, 0:3]} == {(x, y, z) for x in (0, 1) for y in (0, 1) for z in (0, 1)}   # first-use order
+    cube = verts[:8]
+    # smooth normals of a cube's corners point along the diagonal, unit length, outward (faces are wound outward)
+    assert np.allclose(np.linalg.norm(cube[:, 3:6], axis=1), 1, atol=1e-5)
+    assert np.allclose(cube[:, 3:6], (cube[:, 0:3] * 2 - 1) / np.sqrt(3), atol=1e-5)
+    # face winding survives fan triangulation: every cube triangle faces away from the centre
+    p = cube[:, 0:3]
+    for t in tris[:12]:
+        n = np.cross(p[t[1]] - p[t[0]], p[t[2]] - p[t[0]])
+        assert np.dot(n, p[t].mean(0) - 0.5) > 0
+    # the explicit triangle: relative indices, uv and normal taken from the file
+    assert np.allclose(verts[8:, 0:3], [(2, 0, 0), (3, 0, 0), (2, 1, 0)]) and np.allclose(verts[8:, 3:6], (0, 0, 1))
+    assert np.allclose(verts[8:10, 6:8], (0.5, 0.25)) and np.allclose(verts[10, 6:8], (0, 0))
+
+
+@pytest.mark.parametrize("bad,msg", [("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 4\n", "out of range"), ("v 0 0 0\nv 1 0 0\nf 1 2\n", "fewer than 3"),
+                                     ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 x 3\n", "bad face corner"), ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 0 1 2\n", "index 0")])
+def test_obj_loader_rejects_malformed_faces(tmp_path, bad, msg):
+    exe = _build_obj_tool(tmp_path)
+    obj = tmp_path / "bad.obj"
+    obj.write_text(bad)
+    r = subprocess.run([exe, str(obj)], capture_output=True, text=True)
+    assert r.returncode == 1 and msg in r.stdout and "OBJ line" in r.stdout
+    r = subprocess.run([exe, str(tmp_path / "missing.obj")], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open" in r.stdout
+
+
+WINDOW_MAIN = r"""
+// drives the headless RendererWindow the way GLFW would: frames, key state, mouse drag, resize, preview files
+#include <cstdio>
+#include "RendererWindow.hpp"
+using namespace CUDATracer;
+struct Wnd : RendererWindow {
+    using RendererWindow::RendererWindow;
+    const PathTraceSettings& st() { return renderSettings->Get<0>(); }
+};
+#define EXPECT(c) do { if (!(c)) { std::printf("FAILED line %d: %s\n", __LINE__, #c); return 1; } } while (0)
+int main(int argc, char** argv) {
+    try {
+        Wnd w(Scenes::CornellBox(), "t", 64, 40);
+        w.camParam = Scenes::CornellCamera();
+        w.SetPreview(argv[1], 2);
+        w.run(5);
+        EXPECT(w.frameID() == 5);
+        EXPECT(w.frame().size() == 64 * 40 * 4);
+        Math::vec3f p0 = w.camParam.pos;
+        w.keys.w = true; w.Update(); w.keys.w = false;                 // W: 0.1 along front, accumulation restarts
+        EXPECT(w.frameID() == 0);
+        EXPECT(std::fabs(w.camParam.pos.x - (p0.x + 0.1f * w.st().cam.front.x)) < 1e-6f);
+        w.render(); w.render();
+        EXPECT(w.frameID() == 2);
+        w.Update();                                                     // no key: nothing changes
+        EXPECT(w.frameID() == 2);
+        w.mouseMotion(10, 10);                                          // button up: motion is tracked, camera is not touched
+        EXPECT(w.frameID() == 2);
+        float az = w.camParam.azimuth, ze = w.camParam.zenith;
+        w.mouseLeftDown = true; w.mouseMotion(50, 30);
+        EXPECT(w.frameID() == 0);
+        EXPECT(std::fabs(w.camParam.azimuth - (az + 40.f / 400)) < 1e-6f && std::fabs(w.camParam.zenith - (ze + 20.f / 400)) < 1e-6f);
+        w.mouseMotion(50, 30);                                          // no movement: no reset
+        w.render();
+        EXPECT(w.frameID() == 1);
+        w.resize({ 32, 16 });                                           // new buffers, accumulation restarts
+        EXPECT(w.frameID() == 0 && w.st().viewportWidth == 32 && w.st().viewportHeight == 16);
+        w.render();
+        EXPECT(w.frame().size() == 32 * 16 * 4 && w.frameID() == 1);
+        const float* a = w.accumulation();
+        EXPECT(a[3] == 1.0f);                                           // alpha written by the kernel
+        std::printf("OK\n");
+    } catch (const std::exception& e) { std::printf("error: %s\n", e.what()); return 1; }
+    return 0;
+}
+"""
+
+
+@pytest.mark.gpu
+def test_renderer_window_input_resets_accumulation_and_preview_files(tmp_path):
+    src = tmp_path / "wnd.cpp"
+    src.write_text(WINDOW_MAIN)
+    exe = str(tmp_path / "wnd")
+    libdir = os.path.join(ROOT, "cudapathtracer_amd")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(libdir, "cpp"), str(src), "-o", exe, "-L", libdir, "-lmipt",
+                        "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    prefix = str(tmp_path / "prev")
+    r = subprocess.run([exe, prefix], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    for k in (2, 4):
+        body = open(f"{prefix}_{k}.ppm", "rb").read()
+        assert body.startswith(b"P6 64 40 255\n") and len(body) == len(b"P6 64 40 255\n") + 64 * 40 * 3
+    assert not os.path.exists(f"{prefix}_5.ppm")
+
+
+@pytest.mark.gpu
+def test_objscene_app_loads_builds_caches_and_renders(tmp_path):
+    # a 64x64 height-field written as OBJ quads (8 k triangles), rendered twice: second run takes the BVH from the cache
+    n = 64
+    xs = np.linspace(-1.5, 1.5, n + 1)
+    with open(tmp_path / "hf.obj", "w") as f:
+        for z in xs:
+            for x in xs:
+                f.write(f"v {x:.6f} {0.3 + 0.2 * np.sin(3 * x) * np.cos(2 * z):.6f} {z:.6f}\n")
+        for j in range(n):
+            for i in range(n):
+                a = j * (n + 1) + i + 1
+                f.write(f"f {a} {a + n + 1} {a + n + 2} {a + 1}\n")
+    cache = str(tmp_path / "hf.bvh")
+    outs = []
+    for run in range(2):
+        ppm, pfm = str(tmp_path / f"o{run}.ppm"), str(tmp_path / f"o{run}.pfm")
+        r = subprocess.run([os.path.join(APPS, "objscene"), str(tmp_path / "hf.obj"), "96", "64", "4", ppm, pfm, cache],
+                           capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"{2 * n * n} triangles loaded" in r.stdout
+        assert ("from cache" if run else "BVH built") in r.stdout
+        outs.append(open(pfm, "rb").read())
+    hdr = b"PF\n96 64\n-1.0\n"
+    a, b = (np.frombuffer(o[len(hdr):], np.float32) for o in outs)
+    assert np.allclose(a, b, rtol=1e-4, atol=1e-6) and a.mean() > 0.01      # same BVH -> same image (up to add order)

@@ -1,5 +1,7 @@
 """Callers' scene construction (product C++ vs the oracle's independent restatement) and the product's BVH builders,
 checked structurally and functionally with the oracle.  CPU only: host-only scenes need no GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -174,3 +176,34 @@ def test_parallel_build_is_thread_count_independent(ptlib, oracle, monkeypatch):
     b, _ = o.trace_rays(oracle.ISECT_BRUTE, og, dg)
     assert (f["tri"] >= 0).sum() > 5000
     assert ((f["tri"] != b["tri"]) | (f["t"] != b["t"])).sum() <= 10
+
+
+def test_bvh_cache_roundtrip_and_rejection(ptlib, oracle, tmp_path):
+    data = ptlib.builtin_scene(1)
+    path = str(tmp_path / "default.bvh")
+    a = ptlib.Scene(None, data, bvh_cache=path)
+    assert not a.bvh_was_cached and os.path.getsize(path) > 32
+    b = ptlib.Scene(None, data, bvh_cache=path)
+    assert b.bvh_was_cached
+    na, ra = a.bvh(); nb, rb = b.bvh()
+    assert np.array_equal(na.view(np.uint32), nb.view(np.uint32)) and np.array_equal(ra.view(np.uint32), rb.view(np.uint32))
+    # other build parameters or other triangles: the file does not match, the BVH is rebuilt (and the file replaced)
+    c = ptlib.Scene(None, data, bvh_cache=path, max_leaf=2)
+    assert not c.bvh_was_cached
+    assert ptlib.Scene(None, data, bvh_cache=path, max_leaf=2).bvh_was_cached
+    assert not ptlib.Scene(None, ptlib.builtin_scene(0), bvh_cache=path).bvh_was_cached
+    # corrupt structure under a matching key: rejected by the validator, rebuilt
+    d = ptlib.Scene(None, data, bvh_cache=path)
+    assert not d.bvh_was_cached
+    raw = bytearray(open(path, "rb").read())
+    hdr = 32
+    for bad in (np.uint32(0x0FFFFFFF), np.uint32(0), np.uint32(0x80000000 | (15 << 27) | 0x07FFFFF0)):
+        mod = bytearray(raw)
+        mod[hdr + 12 * 4: hdr + 13 * 4] = bad.tobytes()        # root's first child: out of range / cycle / leaf past the end
+        open(path, "wb").write(mod)
+        e = ptlib.Scene(None, data, bvh_cache=path)
+        assert not e.bvh_was_cached
+        ne, _ = e.bvh()
+        assert np.array_equal(ne.view(np.uint32), na.view(np.uint32))
+    open(path, "wb").write(raw[:100])                            # truncated
+    assert not ptlib.Scene(None, data, bvh_cache=path).bvh_was_cached
