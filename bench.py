@@ -5,7 +5,8 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one frame (1 spp) of the workload per GPU.  Default workload = BASELINE.json configs[1]: Cornell box,
-1920x1080, 8 bounces (`--workload default` = configs[2]: DefaultScene + synthetic HDRI, 12 bounces).  With N > 1 the
+1920x1080, 8 bounces (`--workload default` = configs[2]: DefaultScene + synthetic HDRI, 12 bounces; `--workload grid`
+= the configs[4] stand-in: 10 M-triangle displaced grid, 3840x2160, 4 bounces -- the HBM-stressing case).  With N > 1 the
 scene is replicated, rank r renders frame indices r, r+N, ... into a private sum buffer (weak scaling: one frame per
 GPU per step) and ONE RCCL reduce of the accumulation buffers closes the timed region.
 
@@ -32,10 +33,11 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=8)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--workload", default="cornell", choices=["cornell", "default"])
-    p.add_argument("--width", type=int, default=1920)
-    p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--depth", type=int, default=0, help="0 = 8 for cornell, 12 for default (BASELINE.json)")
+    p.add_argument("--workload", default="cornell", choices=["cornell", "default", "grid"])
+    p.add_argument("--width", type=int, default=0, help="0 = 1920 (cornell, default) or 3840 (grid)")
+    p.add_argument("--height", type=int, default=0, help="0 = 1080 (cornell, default) or 2160 (grid)")
+    p.add_argument("--depth", type=int, default=0, help="0 = 8 for cornell, 12 for default, 4 for grid (BASELINE.json)")
+    p.add_argument("--grid-n", type=int, default=2236, help="grid workload: n x n quads = 2 n^2 triangles (2236 -> 10.0 M)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU oracle budget (0 disables cpu_baseline)")
     p.add_argument("--tile-pixels", type=int, default=0)
     p.add_argument("--integrator", type=int, default=0, help="0 persistent wave stacks (default), 1 level-synchronous queues")
@@ -101,14 +103,22 @@ def main():
     import cudapathtracer_amd as pt
     from cudapathtracer_amd import dist as ptdist
 
-    depth = a.depth or (8 if a.workload == "cornell" else 12)
-    W, H = a.width, a.height
+    depth = a.depth or {"cornell": 8, "default": 12, "grid": 4}[a.workload]
+    W = a.width or (3840 if a.workload == "grid" else 1920)
+    H = a.height or (2160 if a.workload == "grid" else 1080)
     if a.workload == "cornell":
         data = pt.builtin_scene(0)
         cam = pt.make_camera(**pt.CORNELL_CAMERA)
-    else:
+    elif a.workload == "default":
         data = pt.builtin_scene(1, pt.synthetic_sky(2048, 1024, 0x5EED))
         cam = pt.make_camera(**pt.DEFAULT_CAMERA)
+    else:
+        # BASELINE.json configs[4] stand-in: displaced grid, one diffuse material, synthetic HDRI
+        v, i = pt.grid_mesh(a.grid_n, 8.0, 1.0, 1)
+        sky = pt.SkyLight(); sky.color[:] = (0.98, 0.97, 0.99); sky.dir[:] = (-0.577, -0.577, -0.577); sky.intensity = 5
+        data = pt.SceneData([(v, i, pt.make_material(color=(0.8, 0.8, 0.8), roughness=0.5, metallic=0.0, opacity=1.0, n=2.5))],
+                            sky, pt.synthetic_sky(2048, 1024, 0x5EED))
+        cam = pt.make_camera((-7.0, 4.0, 0.0), 0.0, 2.0, float(np.float32(np.pi / 3)))
     settings = pt.make_settings(cam, W, H, depth)
 
     torch.cuda.set_device(local)
@@ -169,8 +179,8 @@ def main():
     total_rays, dt = float(rays.item()), float(tmax.item())
 
     if rank == 0:
+        nn, nr = (len(x) for x in sc.bvh())
         if a.integrator == 0:    # one k_wavestack launch per frame traces every ray of the frame
-            nn, nr = (len(x) for x in sc.bvh())
             kernel_name = "mipt::k_wavestack<%s>" % ("true" if nn * 4 + nr * 3 <= 1024 else "false")   # LDS-resident scene?
             sec_rays, sec_ms, sec_launches = float(cnt.rays), prof.ms[0], prof.launches[0]
         else:                    # k_level<false,*> launches carry the non-primary levels
@@ -187,7 +197,8 @@ def main():
             if a.integrator == 0:
                 n_node, n_tri, miss = cpu["n_node_all"], cpu["n_tri_all"], cpu["miss_all"]
         traffic = a.traffic_gb
-        if traffic is None and a.integrator == 0 and (W, H) == (1920, 1080):
+        default_size = (W, H) == ((3840, 2160) if a.workload == "grid" else (1920, 1080)) and (a.workload != "grid" or a.grid_n == 2236)
+        if traffic is None and a.integrator == 0 and default_size and not a.depth:
             # HBM bytes per launch from the committed PMC passes of this same command (scripts/pmc_passes.sh;
             # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, plus WRITE_SIZE)
             try:
@@ -206,12 +217,15 @@ def main():
                     "kernel": kernel_name, "bytes_per_ray": round(b_ray, 1), "n_node_per_ray": round(n_node, 3),
                     "n_tri_per_ray": round(n_tri, 3), "rays_per_launch": round(sec_rays / max(sec_launches, 1), 1),
                     "avg_launch_ms": round(sec_ms / max(sec_launches, 1), 4), "launches": int(sec_launches),
-                    "note": "working set (BVH+triangles) is cache/LDS resident for this workload: algorithmic bytes are served on-chip, so frac is not an HBM utilisation"}
+                    "working_set_mb": round((nn * 64 + nr * 48) / 1e6, 2),
+                    "note": ("working set (BVH+triangles) is cache/LDS resident for this workload: algorithmic bytes are served on-chip, so frac is not an HBM utilisation"
+                             if (nn * 64 + nr * 48) < 32e6 else
+                             "working set exceeds the 32 MB of L2; algorithmic bytes above `traffic` are re-reads served by L2 / Infinity Cache")}
         out = {
             "metric": "Mrays/s (extension+shadow)", "value": round(total_rays / dt / 1e6, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.workload}_{W}x{H}_{depth}bounce_1spp_per_gpu_step", "width": W, "height": H, "max_depth": depth,
+            "config": {"workload": f"{a.workload}_{W}x{H}_{depth}bounce_1spp_per_gpu_step" + (f"_n{a.grid_n}" if a.workload == "grid" else ""), "width": W, "height": H, "max_depth": depth,
                        "triangles": data.triangle_count, "bvh": "sbvh", "rng": "node", "integrator": "wave-stacks" if a.integrator == 0 else "level-queues", "parallelism": f"sample-striding x{world}",
                        "env_map": None if data.env is None else "synthetic 2048x1024"},
             "spp_per_s": round(a.steps * world / dt, 3), "rays_per_step_per_gpu": round(total_rays / a.steps / world, 1),
