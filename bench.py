@@ -42,17 +42,18 @@ def parse():
     p.add_argument("--tile-pixels", type=int, default=0)
     p.add_argument("--integrator", type=int, default=0, help="0 persistent wave stacks (default), 1 level-synchronous queues")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (default); gloo = rehearsal of the N>1 flow through host memory")
+    p.add_argument("--node-width", type=int, default=0, help="BVH node layout: 0 library default, 2 fp32 BVH2, 4 quantised 4-wide")
     p.add_argument("--traffic-gb", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC run (GB)")
     return p.parse_args()
 
 
-def oracle_sample(pt, data, bvh, settings, seconds, threads):
+def oracle_sample(pt, data, bvh, width, settings, seconds, threads):
     """Times the CPU oracle (same flat BVH, node-keyed RNG) on evenly spaced rows of frame 0 and returns its rate
     and the mean node visits / triangle tests per non-primary ray (the figures B_ray is computed from)."""
     from oracle import orc                      # cpu_baseline leg only: checker / reported baseline
     import ctypes as C
     o = orc.Scene(data)
-    o.set_flat_bvh(*bvh)
+    o.set_flat_bvh(*bvh, width)
     W, H = settings.viewportWidth, settings.viewportHeight
 
     def run(rows, depth):
@@ -127,7 +128,7 @@ def main():
     if a.tile_pixels:
         t.set_option("tile_pixels", a.tile_pixels)
     t.set_option("integrator", a.integrator)
-    sc = pt.Scene(t, data)
+    sc = pt.Scene(t, data, node_width=a.node_width)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     ldr = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
@@ -181,7 +182,7 @@ def main():
     if rank == 0:
         nn, nr = (len(x) for x in sc.bvh())
         if a.integrator == 0:    # one k_wavestack launch per frame traces every ray of the frame
-            kernel_name = "mipt::k_wavestack<%s>" % ("true" if nn * 4 + nr * 3 <= 1024 else "false")   # LDS-resident scene?
+            kernel_name = "mipt::k_wavestack<%s>" % ("false, true" if sc.bvh_width == 4 else "true, false" if nn * 4 + nr * 3 <= 1024 else "false, false")   # <LDS scene, 4-wide>
             sec_rays, sec_ms, sec_launches = float(cnt.rays), prof.ms[0], prof.launches[0]
         else:                    # k_level<false,*> launches carry the non-primary levels
             kernel_name = "mipt::k_level<false,*>"
@@ -192,13 +193,13 @@ def main():
         n_node = n_tri = miss = None
         if a.cpu_seconds > 0:
             threads = min(os.cpu_count() or 1, 16)
-            cpu = oracle_sample(pt, data, sc.bvh(), settings, a.cpu_seconds if world == 1 else min(a.cpu_seconds, 3.0), threads)
+            cpu = oracle_sample(pt, data, sc.bvh(), sc.bvh_width, settings, a.cpu_seconds if world == 1 else min(a.cpu_seconds, 3.0), threads)
             n_node, n_tri, miss = cpu["n_node"], cpu["n_tri"], cpu["miss_frac"]
             if a.integrator == 0:
                 n_node, n_tri, miss = cpu["n_node_all"], cpu["n_tri_all"], cpu["miss_all"]
         traffic = a.traffic_gb
         default_size = (W, H) == ((3840, 2160) if a.workload == "grid" else (1920, 1080)) and (a.workload != "grid" or a.grid_n == 2236)
-        if traffic is None and a.integrator == 0 and default_size and not a.depth:
+        if traffic is None and a.integrator == 0 and default_size and not a.depth and not a.node_width:
             # HBM bytes per launch from the committed PMC passes of this same command (scripts/pmc_passes.sh;
             # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, plus WRITE_SIZE)
             try:
@@ -226,7 +227,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.workload}_{W}x{H}_{depth}bounce_1spp_per_gpu_step" + (f"_n{a.grid_n}" if a.workload == "grid" else ""), "width": W, "height": H, "max_depth": depth,
-                       "triangles": data.triangle_count, "bvh": "sbvh", "rng": "node", "integrator": "wave-stacks" if a.integrator == 0 else "level-queues", "parallelism": f"sample-striding x{world}",
+                       "triangles": data.triangle_count, "bvh": "sbvh" + ("-q4" if sc.bvh_width == 4 else ""), "rng": "node", "integrator": "wave-stacks" if a.integrator == 0 else "level-queues", "parallelism": f"sample-striding x{world}",
                        "env_map": None if data.env is None else "synthetic 2048x1024"},
             "spp_per_s": round(a.steps * world / dt, 3), "rays_per_step_per_gpu": round(total_rays / a.steps / world, 1),
             "shadow_rays": 0, "kernel_ms_per_step": round(cnt.kernel_ms / a.steps, 3),

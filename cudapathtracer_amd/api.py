@@ -52,7 +52,7 @@ class SceneDesc(C.Structure):
     _fields_ = [("meshes", C.POINTER(MeshDesc)), ("meshCnt", C.c_uint32), ("sky", SkyLight),
                 ("envMap", C.c_void_p), ("envW", C.c_uint32), ("envH", C.c_uint32),
                 ("bvhBuilder", C.c_uint32), ("maxLeafSize", C.c_uint32), ("splitAlpha", C.c_float), ("sahTriCost", C.c_float),
-                ("bvhCachePath", C.c_char_p)]
+                ("nodeWidth", C.c_uint32), ("bvhCachePath", C.c_char_p)]
 
 
 class Counters(C.Structure):
@@ -88,6 +88,8 @@ lib.mipt_scene_get_bvh.argtypes = [_vp, _vp, C.POINTER(C.c_uint32), _vp, C.POINT
 lib.mipt_scene_triangle_count.argtypes = [_vp]
 lib.mipt_scene_triangle_count.restype = C.c_uint32
 lib.mipt_scene_bvh_was_cached.argtypes = [_vp]
+lib.mipt_scene_bvh_width.argtypes = [_vp]
+lib.mipt_scene_bvh_width.restype = C.c_uint32
 lib.mipt_trace.argtypes = [_vp, _vp, C.POINTER(Settings), _vp, _vp]
 lib.mipt_render.argtypes = [_vp, _vp, C.POINTER(Settings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _vp, _vp]
 lib.mipt_tonemap.argtypes = [_vp, _vp, C.c_float, C.c_uint32, _vp]
@@ -248,7 +250,7 @@ DEFAULT_CAMERA = dict(pos=(-1.0, 1.0, 0.0), azimuth=0.0, zenith=float(np.float32
 
 # ---- handles -----------------------------------------------------------------------------------------------------
 class Scene:
-    def __init__(self, tracer, data, builder=BVH_SBVH, max_leaf=0, split_alpha=0.0, tri_cost=0.0, bvh_cache=None):
+    def __init__(self, tracer, data, builder=BVH_SBVH, max_leaf=0, split_alpha=0.0, tri_cost=0.0, bvh_cache=None, node_width=0):
         """tracer may be None: host-only scene (BVH build + get_bvh), usable without a GPU.
         bvh_cache: path of a BVH cache file (loaded if it matches these triangles and parameters, else written)."""
         self.h = None
@@ -257,11 +259,16 @@ class Scene:
         desc, keep = data.fill_desc(SceneDesc, MeshDesc)
         desc.bvhBuilder, desc.maxLeafSize, desc.splitAlpha, desc.sahTriCost = builder, max_leaf, split_alpha, tri_cost
         desc.bvhCachePath = os.fsencode(bvh_cache) if bvh_cache else None
+        desc.nodeWidth = node_width
         h = _vp()
         rc = lib.mipt_scene_create(tracer.h if tracer else None, C.byref(desc), C.byref(h))
         if rc != 0:
             raise MiptError(f"mipt_scene_create: {rc} {tracer.last_error() if tracer else ''}")
         self.h = h
+
+    @property
+    def bvh_width(self):
+        return int(lib.mipt_scene_bvh_width(self.h))
 
     @property
     def bvh_was_cached(self):

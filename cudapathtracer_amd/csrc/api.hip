@@ -56,6 +56,7 @@ struct mipt_scene {
     void* dNodes = nullptr; void* dRefs = nullptr; void* dShade = nullptr; void* dMats = nullptr; void* dEnv = nullptr;
     std::vector<float> hNodes, hRefs;    // host copies for mipt_scene_get_bvh
     uint32_t nTris = 0;
+    uint32_t bvhWidth = 2;
     bool bvhFromCache = false;
 };
 
@@ -122,7 +123,7 @@ inline float hdot(const float* a, const float* b) { return fmaf(a[2], b[2], fmaf
 struct BvhCacheHeader {
     char magic[8];              // "MIPTBVH1"
     uint64_t key;               // hash of the triangle positions and the build parameters
-    uint32_t nTris, nNodes, nRefs, reserved;
+    uint32_t nTris, nNodes, nRefs, width;
 };
 uint64_t bvh_cache_key(const std::vector<TriPos>& tris, const BvhParams& bp) {
     uint64_t h = 0xcbf29ce484222325ull;
@@ -133,20 +134,21 @@ uint64_t bvh_cache_key(const std::vector<TriPos>& tris, const BvhParams& bp) {
     for (; i + 1 < n; i += 2) mix((uint64_t)w[i] | ((uint64_t)w[i + 1] << 32));
     if (i < n) mix(w[i]);
     uint32_t a, c; memcpy(&a, &bp.splitAlpha, 4); memcpy(&c, &bp.triCost, 4);
-    mix(bp.builder); mix(bp.maxLeafSize); mix(a); mix(c); mix(tris.size());
+    mix(bp.builder); mix(bp.maxLeafSize); mix(a); mix(c); mix(tris.size()); mix(bp.nodeWidth);
     return h;
 }
-bool load_bvh_cache(const char* path, uint64_t key, uint32_t nTris, BvhOut& bo) {
+bool load_bvh_cache(const char* path, uint64_t key, uint32_t nTris, uint32_t width, BvhOut& bo) {
     FILE* f = fopen(path, "rb");
     if (!f) return false;
     BvhCacheHeader h;
-    bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "MIPTBVH1", 8) && h.key == key && h.nTris == nTris &&
+    bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "MIPTBVH1", 8) && h.key == key && h.nTris == nTris && h.width == width &&
               h.nNodes > 0 && h.nNodes < (1u << 27) && h.nRefs < (1u << 27);
     if (ok) {
         bo.nodes.resize((size_t)h.nNodes * 16); bo.refTri.resize(h.nRefs);
         ok = fread(bo.nodes.data(), 64, h.nNodes, f) == h.nNodes && (h.nRefs == 0 || fread(bo.refTri.data(), 4, h.nRefs, f) == h.nRefs);
     }
     fclose(f);
+    bo.width = width;
     return ok && validate_bvh(bo, nTris).empty();
 }
 bool save_bvh_cache(const char* path, uint64_t key, uint32_t nTris, const BvhOut& bo) {
@@ -154,7 +156,7 @@ bool save_bvh_cache(const char* path, uint64_t key, uint32_t nTris, const BvhOut
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) return false;
     BvhCacheHeader h; memcpy(h.magic, "MIPTBVH1", 8); h.key = key; h.nTris = nTris;
-    h.nNodes = (uint32_t)(bo.nodes.size() / 16); h.nRefs = (uint32_t)bo.refTri.size(); h.reserved = 0;
+    h.nNodes = (uint32_t)(bo.nodes.size() / 16); h.nRefs = (uint32_t)bo.refTri.size(); h.width = bo.width;
     bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(bo.nodes.data(), 64, h.nNodes, f) == h.nNodes &&
               (h.nRefs == 0 || fwrite(bo.refTri.data(), 4, h.nRefs, f) == h.nRefs);
     ok = (fclose(f) == 0) && ok;
@@ -306,10 +308,12 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
     if (d->maxLeafSize) bp.maxLeafSize = d->maxLeafSize;
     if (d->splitAlpha > 0.f) bp.splitAlpha = d->splitAlpha;
     if (d->sahTriCost > 0.f) bp.triCost = d->sahTriCost;
+    if (d->nodeWidth) bp.nodeWidth = d->nodeWidth;
+    if (bp.nodeWidth != 2 && bp.nodeWidth != 4) return fail(t, MIPT_E_INVALID, "nodeWidth must be 0, 2 or 4");
     BvhOut bo;
     const bool useCache = d->bvhCachePath && d->bvhCachePath[0];
     const uint64_t cacheKey = useCache ? bvh_cache_key(tris, bp) : 0;
-    const bool cached = useCache && load_bvh_cache(d->bvhCachePath, cacheKey, (uint32_t)tris.size(), bo);
+    const bool cached = useCache && load_bvh_cache(d->bvhCachePath, cacheKey, (uint32_t)tris.size(), bp.nodeWidth, bo);
     if (!cached) {
         bo = BvhOut();
         std::string berr = build_bvh(tris, bp, bo);
@@ -319,7 +323,7 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
     }
 
     mipt_scene* s = new mipt_scene();
-    s->t = t; s->nTris = (uint32_t)tris.size(); s->bvhFromCache = cached;
+    s->t = t; s->nTris = (uint32_t)tris.size(); s->bvhFromCache = cached; s->bvhWidth = bo.width;
     s->hNodes = std::move(bo.nodes);
     s->hRefs.resize(bo.refTri.size() * 12);
     for (size_t r = 0; r < bo.refTri.size(); r++) {
@@ -355,6 +359,7 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
     s->dev.envW = s->dEnv ? d->envW : 0; s->dev.envH = s->dEnv ? d->envH : 0;
     memcpy(s->dev.skyColor, d->sky.color, 12); memcpy(s->dev.skyDir, d->sky.dir, 12); s->dev.skyIntensity = d->sky.intensity;
     s->dev.nNodes = (uint32_t)(s->hNodes.size() / 16); s->dev.nRefs = (uint32_t)bo.refTri.size();
+    s->dev.wide = bo.width == 4 ? 1u : 0u;
     if (t) hipDeviceSynchronize();
     *out = s;
     return MIPT_OK;
@@ -380,6 +385,7 @@ int mipt_scene_get_bvh(const mipt_scene* s, float* nodes, uint32_t* n_nodes, flo
     return MIPT_OK;
 }
 uint32_t mipt_scene_triangle_count(const mipt_scene* s) { return s ? s->nTris : 0; }
+uint32_t mipt_scene_bvh_width(const mipt_scene* s) { return s ? s->bvhWidth : 0; }
 int mipt_scene_bvh_was_cached(const mipt_scene* s) { return s && s->bvhFromCache ? 1 : 0; }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -372,6 +372,86 @@ private:
     }
 };
 
+// ---- BVH2 -> quantised 4-wide nodes ------------------------------------------------------------------------------
+struct WideChild { uint32_t ref; Box b; };
+
+class Collapser {
+public:
+    Collapser(const std::vector<float>& n2, std::vector<float>& n4) : N2(n2), N4(n4) {}
+    uint32_t maxDepth = 0;
+    // returns the worst-case number of stack entries below (and including the pushes of) this node
+    uint32_t build(uint32_t node2, uint32_t level) {
+        maxDepth = std::max(maxDepth, level);
+        WideChild ch[4]; int n = 0;
+        auto child_of = [&](uint32_t nd, int which) {
+            WideChild c; const float* P = &N2[(size_t)nd * 16];
+            memcpy(c.b.mn, P + which * 6, 12); memcpy(c.b.mx, P + which * 6 + 3, 12); memcpy(&c.ref, P + 12 + which, 4);
+            return c;
+        };
+        ch[n++] = child_of(node2, 0); ch[n++] = child_of(node2, 1);
+        while (n < 4) {                                  // open the inner child with the largest area
+            int best = -1; float bestA = -1.f;
+            for (int i = 0; i < n; i++) if (!(ch[i].ref & kLeafFlag)) { float a = ch[i].b.area(); if (a > bestA) { bestA = a; best = i; } }
+            if (best < 0) break;
+            uint32_t nd = ch[best].ref;
+            ch[best] = child_of(nd, 0); ch[n++] = child_of(nd, 1);
+        }
+        // zero-reference leaves (the builder's root padding) are not children
+        int m = 0;
+        for (int i = 0; i < n; i++) if (!((ch[i].ref & kLeafFlag) && ((ch[i].ref >> 27) & 0xFu) == 0)) ch[m++] = ch[i];
+        n = m;
+        const uint32_t self = (uint32_t)(N4.size() / 16);
+        N4.resize(N4.size() + 16, 0.f);
+        uint32_t need = 0;
+        uint32_t refs[4] = { kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef };
+        for (int i = 0; i < n; i++) {
+            if (ch[i].ref & kLeafFlag) refs[i] = ch[i].ref;
+            else { refs[i] = (uint32_t)(N4.size() / 16); need = std::max(need, build(ch[i].ref, level + 1)); }
+        }
+        quantise(self, ch, n, refs);
+        return need + (n > 0 ? (uint32_t)n - 1u : 0u);
+    }
+
+private:
+    const std::vector<float>& N2; std::vector<float>& N4;
+
+    void quantise(uint32_t self, const WideChild* ch, int n, const uint32_t* refs) {
+        Box nb; for (int i = 0; i < n; i++) if (ch[i].b.valid()) nb.grow(ch[i].b);
+        if (!nb.valid()) for (int a = 0; a < 3; a++) nb.mn[a] = nb.mx[a] = 0.f;
+        uint32_t e[3]; uint8_t qlo[3][4] = {}, qhi[3][4] = {};
+        for (int a = 0; a < 3; a++) {
+            const float origin = nb.mn[a];
+            // smallest power of two with 255 * scale >= extent; kept inside [2^-60, 2^100] so no product with a ray's
+            // inverse direction (<= 2^80) leaves the normal range
+            int ex = 127 - 60;
+            const float ext = nb.mx[a] - origin;
+            while (ex < 227 && 255.0f * scale_of((uint32_t)ex) < ext) ex++;
+            for (;; ex++) {      // widen until every child plane fits (fp32 rounding of the extent can cost one step)
+                bool ok = true;
+                const float sc = scale_of((uint32_t)ex);
+                for (int i = 0; i < n && ok; i++) {
+                    if (!ch[i].b.valid()) { qlo[a][i] = 0; qhi[a][i] = 0; continue; }
+                    int lo = (int)std::floor((ch[i].b.mn[a] - origin) / sc); lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
+                    while (lo > 0 && std::fma((float)lo, sc, origin) > ch[i].b.mn[a]) lo--;
+                    int hi = (int)std::ceil((ch[i].b.mx[a] - origin) / sc); hi = hi < 0 ? 0 : hi;
+                    while (hi <= 255 && std::fma((float)hi, sc, origin) < ch[i].b.mx[a]) hi++;
+                    if (hi > 255 || std::fma((float)lo, sc, origin) > ch[i].b.mn[a]) { ok = false; break; }
+                    qlo[a][i] = (uint8_t)lo; qhi[a][i] = (uint8_t)hi;
+                }
+                if (ok || ex >= 227) break;
+            }
+            e[a] = (uint32_t)ex;
+        }
+        float* P = &N4[(size_t)self * 16];
+        memcpy(P, nb.mn, 12);
+        const uint32_t ebits = e[0] | (e[1] << 8) | (e[2] << 16);
+        memcpy(P + 3, &ebits, 4);
+        for (int a = 0; a < 3; a++) { memcpy(P + 4 + a, qlo[a], 4); memcpy(P + 7 + a, qhi[a], 4); }
+        memcpy(P + 12, refs, 16);
+    }
+    static float scale_of(uint32_t e) { uint32_t b = e << 23; float f; memcpy(&f, &b, 4); return f; }
+};
+
 }  // namespace
 
 std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOut& out) {
@@ -380,26 +460,48 @@ std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOu
     if (const char* e = std::getenv("MIPT_BUILD_THREADS")) threads = std::atoi(e);
     threads = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
     g_spare.store(threads - 1);
+    if (p.nodeWidth != 2 && p.nodeWidth != 4) return "nodeWidth must be 2 or 4";
     Builder b(tris, p, out);
-    return b.run();
+    std::string err = b.run();
+    if (!err.empty()) return err;
+    out.width = 2; out.stackNeed = out.maxDepth + 2;
+    if (p.nodeWidth == 4) {
+        std::vector<float> wide;
+        wide.reserve(out.nodes.size() / 2);
+        Collapser c(out.nodes, wide);
+        const uint32_t need = c.build(0, 0) + 1;                 // + the sentinel
+        if (need > kMaxWideStack) return "4-wide BVH needs a deeper traversal stack than the device has (use nodeWidth 2)";
+        out.nodes.swap(wide);
+        out.width = 4; out.maxDepth = c.maxDepth; out.stackNeed = need;
+    }
+    return "";
 }
 
 std::string validate_bvh(BvhOut& out, uint32_t nTris) {
     const size_t nNodes = out.nodes.size() / 16, nRefs = out.refTri.size();
     if (out.nodes.size() % 16 || nNodes == 0) return "node array is empty or not a multiple of 16 floats";
     if (nNodes >= kLeafFlag || nRefs >= (1u << 27)) return "too many nodes or references";
+    if (out.width != 2 && out.width != 4) return "unknown node layout";
+    const bool wide = out.width == 4;
+    const int fan = wide ? 4 : 2;
     for (uint32_t t : out.refTri) if (t >= nTris) return "reference to a triangle out of range";
     std::vector<uint8_t> seenNode(nNodes, 0), seenTri(nTris, 0);
     std::vector<std::pair<uint32_t, uint32_t>> todo{ {0u, 0u} };    // (node, level)
+    std::vector<uint32_t> order; order.reserve(nNodes);             // discovery order: parents before children
     seenNode[0] = 1;
-    size_t visited = 0; uint32_t deepest = 0;
+    uint32_t deepest = 0;
     while (!todo.empty()) {
         auto [n, level] = todo.back(); todo.pop_back();
-        visited++;
-        if (level >= kMaxBvhDepth) return "BVH deeper than the device traversal stack";
+        order.push_back(n);
         deepest = std::max(deepest, level);
-        uint32_t r[2]; memcpy(r, &out.nodes[(size_t)n * 16 + 12], 8);
-        for (int c = 0; c < 2; c++) {
+        const float* P = &out.nodes[(size_t)n * 16];
+        uint32_t r[4]; memcpy(r, P + 12, 16);
+        if (wide) {
+            uint32_t eb; memcpy(&eb, P + 3, 4);
+            for (int a = 0; a < 3; a++) { uint32_t e = (eb >> (8 * a)) & 0xFFu; if (e < 67 || e > 227) return "quantisation exponent out of range"; }
+            for (int a = 0; a < 3; a++) if (!std::isfinite(P[a])) return "node origin is not finite";
+        }
+        for (int c = 0; c < fan; c++) {
             if (r[c] & kLeafFlag) {
                 const uint32_t cnt = (r[c] >> 27) & 0xFu, first = r[c] & 0x07FFFFFFu;
                 if ((size_t)first + cnt > nRefs) return "leaf range out of bounds";
@@ -412,9 +514,23 @@ std::string validate_bvh(BvhOut& out, uint32_t nTris) {
             }
         }
     }
-    if (visited != nNodes) return "unreachable nodes";
+    if (order.size() != nNodes) return "unreachable nodes";
     for (uint32_t t = 0; t < nTris; t++) if (!seenTri[t]) return "a triangle is referenced by no leaf";
+    // worst-case traversal stack: a node leaves (children - 1) entries behind while its deepest child is walked
+    std::vector<uint32_t> need(nNodes, 0);
+    for (size_t k = order.size(); k-- > 0;) {
+        const uint32_t n = order[k];
+        uint32_t r[4]; memcpy(r, &out.nodes[(size_t)n * 16 + 12], 16);
+        uint32_t below = 0; int kids = 0;
+        for (int c = 0; c < fan; c++) {
+            if (r[c] & kLeafFlag) { if (!wide || r[c] != kEmptyRef) kids++; }
+            else { kids++; below = std::max(below, need[r[c]]); }
+        }
+        need[n] = below + (kids > 0 ? (uint32_t)kids - 1u : 0u);
+    }
     out.maxDepth = deepest;
+    out.stackNeed = need[0] + 1;                                     // + the sentinel
+    if (out.stackNeed > (wide ? kMaxWideStack : kMaxBvhDepth)) return "BVH needs a deeper traversal stack than the device has";
     out.duplicates = (uint32_t)(nRefs - nTris);
     return "";
 }

@@ -5,6 +5,14 @@
 //   ref   = uint32: bit31 set -> leaf, bits 27..30 = reference count (<= 15), bits 0..26 = first reference;
 //           bit31 clear -> index of an inner node.  Node 0 is the root and is always an inner node.
 //   refTri[i] = global triangle id of reference i (a triangle may be referenced by several leaves: spatial splits).
+//
+// Wide layout (BvhParams::nodeWidth = 4, "Q4"): the BVH2 is collapsed to 4 children per node and the child boxes are
+// quantised to 8 bits per plane relative to the node's own box -- still 64 bytes per node, about half as many node
+// visits per ray:
+//   node  = [origin xyz (3 floats)][ex | ey<<8 | ez<<16 : biased exponents, scale = 2^(e-127)]
+//           [qlo.x of children 0..3 (4 bytes)][qlo.y][qlo.z][qhi.x][qhi.y][qhi.z][0][0]
+//           [ref0][ref1][ref2][ref3]                              (unused child = kEmptyRef)
+//   child plane = origin + q * scale, rounded outward so the quantised box contains the child's box.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -24,6 +32,7 @@ struct BvhParams {
     float    nodeCost = 1.0f;    // getNodeCost(n) = nodeCost * n
     float    triCost = 1.5f;     // getTriangleCost(n) = triCost * n
     uint32_t minLeafSize = 1;
+    uint32_t nodeWidth = 2;      // 2: fp32 BVH2 nodes, 4: quantised 4-wide nodes
 };
 
 struct BvhOut {
@@ -31,10 +40,14 @@ struct BvhOut {
     std::vector<uint32_t> refTri;    // per reference
     uint32_t maxDepth = 0;           // deepest inner-node level (root = 0)
     uint32_t duplicates = 0;         // references - triangles
+    uint32_t width = 2;              // node layout: 2 or 4 (see above)
+    uint32_t stackNeed = 0;          // upper bound of traversal-stack entries a ray can need (incl. the sentinel)
 };
 
 constexpr uint32_t kMaxBvhDepth = 64;       // traversal stack capacity on the device
+constexpr uint32_t kMaxWideStack = 96;      // traversal stack capacity of the 4-wide kernels
 constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kEmptyRef = 0x80000000u; // 4-wide nodes: "no child" (a leaf of zero references)
 inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return kLeafFlag | (count << 27) | first; }
 
 // returns empty string on success, otherwise an error message
@@ -43,6 +56,6 @@ std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOu
 // Structural check of a flat BVH that did not come straight from build_bvh (a cache file): every index in range, the
 // nodes form one tree rooted at node 0 (each node reached exactly once), depth below the device stack, every triangle
 // referenced.  Sets out.maxDepth / out.duplicates.  Returns empty string when the BVH is safe to traverse.
-std::string validate_bvh(BvhOut& out, uint32_t nTris);
+std::string validate_bvh(BvhOut& out, uint32_t nTris);     // out.width selects the layout
 
 }  // namespace mipt

@@ -7,6 +7,7 @@ namespace mipt {
 
 // Scene as the kernels see it.  Everything is flat, 16-byte aligned float4 streams in HBM:
 //   nodes : 4 x float4 per BVH2 node (both children's boxes + two child refs)     64 B
+//           or, when `wide` is set, per quantised 4-wide node (bvh_builder.h)     64 B
 //   refs  : 3 x float4 per triangle reference (v0|triId, e1|meshId, e2|0)          48 B
 //   shade : 3 x float4 per triangle (unit vertex normals n0|meshId, n1, n2)        48 B, touched only for the winning hit
 //   mats  : 3 x float4 per mesh (color|roughness, metallic opacity n emissiveStrength, emissiveColor|0)
@@ -19,6 +20,7 @@ struct SceneDev {
     uint32_t envW, envH;
     float skyColor[3]; float skyDir[3]; float skyIntensity;
     uint32_t nNodes, nRefs;
+    uint32_t wide;            // 0: BVH2 nodes, 1: quantised 4-wide nodes
 };
 
 // Per-frame constants computed once on the host (CUDATracerProg.cu:369-397 computes them per thread).

@@ -18,6 +18,8 @@ constexpr int kBlock = 256;
 constexpr uint32_t kLeaf = 0x80000000u;
 constexpr uint32_t kTerm = 0xFFFFFFFFu;
 constexpr int kStackCap = 64;      // == kMaxBvhDepth of the builder
+constexpr int kWideStackCap = 96;  // == kMaxWideStack of the builder (4-wide nodes push up to three entries per level)
+constexpr uint32_t kEmptyRef = 0x80000000u;
 constexpr int kLdsStack = 8;       // entries per lane kept in LDS; deeper entries spill to scratch
 
 struct HitRec { float t, u, v; int ref; int tri; bool front; };   // ref = reference index, tri = global triangle id
@@ -110,6 +112,79 @@ MIPT_DEV HitRec traverse(NodePtr nodes, RefPtr refs, v3 o, v3 d, uint32_t* ldsSt
                 cur = first;
             } else {
                 MIPT_STACK_POP(ldsStack, deep, tsp, cur);
+            }
+        }
+        if (cur == kTerm) break;
+        uint32_t cnt = (cur >> 27) & 0xFu, first = cur & 0x07FFFFFFu;
+        for (uint32_t i = first; i < first + cnt; i++) {
+            auto T = refs + (size_t)i * 3;
+            float4 a = T[0], b = T[1], c = T[2];
+            float tt, uu, vv; bool ff;
+            int id = (int)__float_as_uint(a.w);
+            if (mt_test(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) { h.t = tt; h.u = uu; h.v = vv; h.front = ff; h.ref = (int)i; h.tri = id; }
+        }
+        MIPT_STACK_POP(ldsStack, deep, tsp, cur);
+    }
+    return h;
+}
+
+// One visit of a quantised 4-wide node (layout: bvh_builder.h).  The ray is moved into the node's quantised frame
+// (t = q * (idir * scale) + (origin - o) * idir), so a child plane costs one byte->float conversion and one FMA.
+// Children that are hit come back sorted by entry distance (s0 nearest); returns how many were hit.
+#define MIPT_CE(ta_, ra_, tb_, rb_) do { if ((tb_) < (ta_)) { float t_ = (ta_); (ta_) = (tb_); (tb_) = t_; uint32_t r_ = (ra_); (ra_) = (rb_); (rb_) = r_; } } while (0)
+MIPT_DEV int wide_visit(const RayPre& r, float4 n0, float4 n1, float4 n2, float4 n3, float hitT,
+                        uint32_t& s0, uint32_t& s1, uint32_t& s2, uint32_t& s3) {
+    const uint32_t eb = __float_as_uint(n0.w);
+    const float ix = r.idir.x * __uint_as_float((eb & 0xFFu) << 23);
+    const float iy = r.idir.y * __uint_as_float(((eb >> 8) & 0xFFu) << 23);
+    const float iz = r.idir.z * __uint_as_float(((eb >> 16) & 0xFFu) << 23);
+    const float ox = (n0.x - r.o.x) * r.idir.x, oy = (n0.y - r.o.y) * r.idir.y, oz = (n0.z - r.o.z) * r.idir.z;
+    const uint32_t lx = __float_as_uint(n1.x), ly = __float_as_uint(n1.y), lz = __float_as_uint(n1.z);
+    const uint32_t hx = __float_as_uint(n1.w), hy = __float_as_uint(n2.x), hz = __float_as_uint(n2.y);
+    float t[4]; uint32_t ref[4] = { __float_as_uint(n3.x), __float_as_uint(n3.y), __float_as_uint(n3.z), __float_as_uint(n3.w) };
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int sh = 8 * i;
+        float tlx = ffma((float)((lx >> sh) & 0xFFu), ix, ox), thx = ffma((float)((hx >> sh) & 0xFFu), ix, ox);
+        float tly = ffma((float)((ly >> sh) & 0xFFu), iy, oy), thy = ffma((float)((hy >> sh) & 0xFFu), iy, oy);
+        float tlz = ffma((float)((lz >> sh) & 0xFFu), iz, oz), thz = ffma((float)((hz >> sh) & 0xFFu), iz, oz);
+        float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tlx, thx), __builtin_fminf(tly, thy)),
+                                     __builtin_fmaxf(__builtin_fminf(tlz, thz), 0.0f));
+        float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tlx, thx), __builtin_fmaxf(tly, thy)),
+                                     __builtin_fminf(__builtin_fmaxf(tlz, thz), hitT));
+        const bool hit = tmin <= tmax && ref[i] != kEmptyRef;
+        t[i] = hit ? tmin : __builtin_inff();
+        n += hit ? 1 : 0;
+    }
+    MIPT_CE(t[0], ref[0], t[1], ref[1]); MIPT_CE(t[2], ref[2], t[3], ref[3]);
+    MIPT_CE(t[0], ref[0], t[2], ref[2]); MIPT_CE(t[1], ref[1], t[3], ref[3]);
+    MIPT_CE(t[1], ref[1], t[2], ref[2]);
+    s0 = ref[0]; s1 = ref[1]; s2 = ref[2]; s3 = ref[3];
+    return n;
+}
+
+// Closest hit on the 4-wide layout: nearest hit child first, the others pushed farthest-first.
+template <typename NodePtr, typename RefPtr>
+MIPT_DEV HitRec traverse_wide(NodePtr nodes, RefPtr refs, v3 o, v3 d, uint32_t* ldsStack) {
+    RayPre r = ray_pre(o, d);
+    HitRec h; h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
+    uint32_t deep[kWideStackCap - kLdsStack];
+    int tsp = 0;
+    MIPT_STACK_PUSH(ldsStack, deep, tsp, kTerm);
+    uint32_t cur = 0;
+    while (true) {
+        while (!(cur & kLeaf)) {
+            auto N = nodes + (size_t)cur * 4;
+            float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+            uint32_t s0, s1, s2, s3;
+            const int n = wide_visit(r, n0, n1, n2, n3, h.t, s0, s1, s2, s3);
+            if (n == 0) { MIPT_STACK_POP(ldsStack, deep, tsp, cur); }
+            else {
+                if (n > 3) MIPT_STACK_PUSH(ldsStack, deep, tsp, s3);
+                if (n > 2) MIPT_STACK_PUSH(ldsStack, deep, tsp, s2);
+                if (n > 1) MIPT_STACK_PUSH(ldsStack, deep, tsp, s1);
+                cur = s0;
             }
         }
         if (cur == kTerm) break;
@@ -300,7 +375,8 @@ __global__ void __launch_bounds__(kBlock) k_level(LevelArgs A) {
             }
             if (A.pixelRays) atomicAdd(A.pixelRays + pix, 1u);
             HitRec h = LDS_SCENE ? traverse((const float4*)ldsScene, (const float4*)ldsScene + A.S.nNodes * 4, o, d, ldsStack + threadIdx.x)
-                                 : traverse(A.S.nodes, A.S.refs, o, d, ldsStack + threadIdx.x);
+                       : A.S.wide ? traverse_wide(A.S.nodes, A.S.refs, o, d, ldsStack + threadIdx.x)
+                                  : traverse(A.S.nodes, A.S.refs, o, d, ldsStack + threadIdx.x);
             if (h.ref < 0) {
                 add_sample(A.sample, pix, beta * on_miss(A.S, d));
             } else {
@@ -345,7 +421,7 @@ __global__ void __launch_bounds__(kBlock) k_level(LevelArgs A) {
 }
 
 void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s) {
-    const bool lds = a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec;
+    const bool lds = !a.S.wide && a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec;
     if (primary) { if (lds) hipLaunchKernelGGL((k_level<true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
                    else hipLaunchKernelGGL((k_level<true, false>), dim3(blocks), dim3(kBlock), 0, s, a); }
     else { if (lds) hipLaunchKernelGGL((k_level<false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
@@ -391,7 +467,7 @@ MIPT_DEV void load_ref(const float4* lds, const float4* glb, uint32_t i, float4&
     else { const float4* T = glb + (size_t)i * 3; a = T[0]; b = T[1]; c = T[2]; }
 }
 
-template <bool LDS_SCENE>
+template <bool LDS_SCENE, bool WIDE>
 __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     constexpr int kSqCap = SqCap<LDS_SCENE>::value;
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
@@ -429,7 +505,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     HitRec h; h.t = __builtin_inff(); h.u = h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
     uint32_t cur = kTerm;
     uint32_t* const lstk = ldsStack + threadIdx.x;
-    uint32_t deep[kStackCap - kLdsStack];
+    uint32_t deep[(WIDE ? kWideStackCap : kStackCap) - kLdsStack];
     int tsp = 0;
     uint32_t traced = 0;
 
@@ -551,6 +627,18 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
             while (!(cur & kLeaf)) {
                 float4 n0, n1, n2, n3;
                 load_node<LDS_SCENE>(ldsNodes, A.S.nodes, cur, n0, n1, n2, n3);
+                if constexpr (WIDE) {
+                    uint32_t s0_, s1_, s2_, s3_;
+                    const int nh = wide_visit(r, n0, n1, n2, n3, h.t, s0_, s1_, s2_, s3_);
+                    if (nh == 0) { MIPT_STACK_POP(lstk, deep, tsp, cur); }
+                    else {
+                        if (nh > 3) MIPT_STACK_PUSH(lstk, deep, tsp, s3_);
+                        if (nh > 2) MIPT_STACK_PUSH(lstk, deep, tsp, s2_);
+                        if (nh > 1) MIPT_STACK_PUSH(lstk, deep, tsp, s1_);
+                        cur = s0_;
+                    }
+                    continue;
+                }
                 float t0, t1;
                 bool h0 = slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, h.t, t0);
                 bool h1 = slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, h.t, t1);
@@ -607,9 +695,10 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
 }
 
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
-    const bool lds = a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec;
-    if (lds) hipLaunchKernelGGL((k_wavestack<true>), dim3(blocks), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((k_wavestack<false>), dim3(blocks), dim3(kBlock), 0, s, a);
+    const bool lds = !a.S.wide && a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec;
+    if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+    else if (lds) hipLaunchKernelGGL((k_wavestack<true, false>), dim3(blocks), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((k_wavestack<false, false>), dim3(blocks), dim3(kBlock), 0, s, a);
 }
 
 // =================================================================================================================
@@ -656,7 +745,8 @@ __global__ void __launch_bounds__(kBlock) k_dfs(DfsArgs A) {
             // ---- LaunchRayRecur entry (:428-531)
             if (ttl <= 0) { ret = mk3(0, 0, 0); entering = false; continue; }
             traced++;
-            HitRec h = traverse(A.S.nodes, A.S.refs, o, d, ldsStack + threadIdx.x);
+            HitRec h = A.S.wide ? traverse_wide(A.S.nodes, A.S.refs, o, d, ldsStack + threadIdx.x)
+                                : traverse(A.S.nodes, A.S.refs, o, d, ldsStack + threadIdx.x);
             if (h.ref < 0) { ret = on_miss(A.S, d); entering = false; continue; }
             Surface sf = surface_at(A.S, o, d, h);
             Material mat = load_material(A.S, sf.mesh);
@@ -768,7 +858,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(SceneDev S, const float* 
     if (i >= n) return;
     v3 ro = mk3(o[(size_t)i * 3], o[(size_t)i * 3 + 1], o[(size_t)i * 3 + 2]);
     v3 rd = mk3(d[(size_t)i * 3], d[(size_t)i * 3 + 1], d[(size_t)i * 3 + 2]);
-    HitRec h = traverse(S.nodes, S.refs, ro, rd, ldsStack + threadIdx.x);
+    HitRec h = S.wide ? traverse_wide(S.nodes, S.refs, ro, rd, ldsStack + threadIdx.x) : traverse(S.nodes, S.refs, ro, rd, ldsStack + threadIdx.x);
     HitOut r; r.t = h.t; r.u = h.u; r.v = h.v; r.front = h.front ? 1 : 0;
     if (h.ref >= 0) {
         r.tri = h.tri;

@@ -51,6 +51,9 @@ typedef struct {
     uint32_t maxLeafSize;                               /* 0 = default (4); at most 15 */
     float    splitAlpha;                                /* SBVH spatial-split threshold; 0 = reference default 1e-5 */
     float    sahTriCost;                                /* SAH cost of one triangle test relative to a node visit; 0 = default (1.5) */
+    uint32_t nodeWidth;                                 /* 0 = default (2); 2 = fp32 BVH2 nodes; 4 = the BVH2 collapsed to 4 children
+                                                           per node with child boxes quantised to 8 bits per plane (still 64 B
+                                                           per node, about half the node visits: for scenes larger than L2) */
     const char* bvhCachePath;                           /* NULL, or a file: if it holds the BVH of exactly these triangles and
                                                            build parameters it is loaded (structure re-validated) instead of
                                                            building; otherwise the BVH is built and written there.  No
@@ -102,6 +105,10 @@ void mipt_scene_destroy(mipt_scene*);
  * refs = 12 floats each [v0 xyz, triId][e1 xyz, meshId][e2 xyz, 0].  Pass NULL buffers to query the counts. */
 int  mipt_scene_get_bvh(const mipt_scene*, float* nodes, uint32_t* n_nodes, float* refs, uint32_t* n_refs);
 uint32_t mipt_scene_triangle_count(const mipt_scene*);
+uint32_t mipt_scene_bvh_width(const mipt_scene*);           /* 2 or 4: node layout of mipt_scene_get_bvh's `nodes` (4-wide: 16 floats =
+                                                             * [origin xyz][ex|ey<<8|ez<<16][qlo.x qlo.y qlo.z qhi.x qhi.y qhi.z: 4 bytes each,
+                                                             * one per child][0][0][ref0..ref3]; plane = origin + q * 2^(e-127); unused child
+                                                             * = 0x80000000) */
 int  mipt_scene_bvh_was_cached(const mipt_scene*);          /* 1 if the BVH came from desc.bvhCachePath, 0 if it was built */
 
 /* ---- the hot path: PathTracer::Trace (CUDATracer.hpp:352-358; CUDATracerProg.cu:937-963) -------------------

@@ -411,6 +411,7 @@ struct orc_scene {
     std::vector<uint32_t> triMesh, triLocal;
     // product's flat BVH
     std::vector<float> fnodes, ftris;
+    uint32_t fwidth = 2;             // 2: BVH2 nodes, 4: quantised 4-wide nodes
 };
 
 namespace {
@@ -551,9 +552,67 @@ Hit isect_flat(const orc_scene& s, v3 o, v3 d, Counters* c) {
     }
     return best;
 }
+// --- product 4-wide quantised layout: node = [origin xyz][ex|ey<<8|ez<<16][qlo.x qlo.y qlo.z qhi.x qhi.y qhi.z: one byte
+//     per child][0][0][ref0..ref3].  The ray is moved into the node's quantised frame exactly as the kernel does
+//     (kernels.hip wide_visit): t = q * (idir * 2^(e-127)) + (origin - o) * idir.  Hit children are visited nearest
+//     first (5-exchange sorting network, swap iff tb < ta), the others pushed farthest first. ---
+inline float ubits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c) {
+    RayPre r = ray_pre(o, d);
+    Hit best; best.t = INFINITY; best.tri = -1; best.u = best.v = 0; best.front = false;
+    if (s.fnodes.empty()) return best;
+    uint32_t stack[256]; int sp = 0;
+    uint32_t cur = 0;
+    while (true) {
+        if (cur & 0x80000000u) {
+            uint32_t cnt = (cur >> 27) & 0xF, first = cur & 0x07FFFFFFu;
+            for (uint32_t i = first; i < first + cnt; i++) {
+                const float* T = &s.ftris[(size_t)i * 12]; c->tris++;
+                float tt, uu, vv; bool ff;
+                if (mt_test(o, d, ld3(T), ld3(T + 4), ld3(T + 8), best.t, &tt, &uu, &vv, &ff, fbits(T[3]), best.tri)) {
+                    best.t = tt; best.u = uu; best.v = vv; best.front = ff; best.tri = fbits(T[3]);
+                }
+            }
+        } else {
+            const float* N = &s.fnodes[(size_t)cur * 16]; c->nodes++;
+            const uint32_t eb = (uint32_t)fbits(N[3]);
+            const float ix = r.idir.x * ubits((eb & 0xFFu) << 23);
+            const float iy = r.idir.y * ubits(((eb >> 8) & 0xFFu) << 23);
+            const float iz = r.idir.z * ubits(((eb >> 16) & 0xFFu) << 23);
+            const float ox = (N[0] - r.o.x) * r.idir.x, oy = (N[1] - r.o.y) * r.idir.y, oz = (N[2] - r.o.z) * r.idir.z;
+            const uint32_t lx = (uint32_t)fbits(N[4]), ly = (uint32_t)fbits(N[5]), lz = (uint32_t)fbits(N[6]);
+            const uint32_t hx = (uint32_t)fbits(N[7]), hy = (uint32_t)fbits(N[8]), hz = (uint32_t)fbits(N[9]);
+            float t[4]; uint32_t ref[4]; int n = 0;
+            for (int i = 0; i < 4; i++) {
+                const int sh = 8 * i;
+                ref[i] = (uint32_t)fbits(N[12 + i]);
+                float tlx = ffma((float)((lx >> sh) & 0xFFu), ix, ox), thx = ffma((float)((hx >> sh) & 0xFFu), ix, ox);
+                float tly = ffma((float)((ly >> sh) & 0xFFu), iy, oy), thy = ffma((float)((hy >> sh) & 0xFFu), iy, oy);
+                float tlz = ffma((float)((lz >> sh) & 0xFFu), iz, oz), thz = ffma((float)((hz >> sh) & 0xFFu), iz, oz);
+                float tmin = fmax_(fmax_(fmin_(tlx, thx), fmin_(tly, thy)), fmax_(fmin_(tlz, thz), 0.0f));
+                float tmax = fmin_(fmin_(fmax_(tlx, thx), fmax_(tly, thy)), fmin_(fmax_(tlz, thz), best.t));
+                const bool hit = tmin <= tmax && ref[i] != 0x80000000u;
+                t[i] = hit ? tmin : INFINITY;
+                n += hit ? 1 : 0;
+            }
+            auto ce = [&](int a, int b) { if (t[b] < t[a]) { std::swap(t[a], t[b]); std::swap(ref[a], ref[b]); } };
+            ce(0, 1); ce(2, 3); ce(0, 2); ce(1, 3); ce(1, 2);
+            if (n > 0) {
+                if (n > 3) stack[sp++] = ref[3];
+                if (n > 2) stack[sp++] = ref[2];
+                if (n > 1) stack[sp++] = ref[1];
+                cur = ref[0];
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return best;
+}
 inline Hit isect(const orc_scene& s, int mode, v3 o, v3 d, Counters* c) {
     c->rays++;
-    Hit h = mode == ORC_ISECT_REF ? isect_ref(s, o, d, c) : mode == ORC_ISECT_FLAT ? isect_flat(s, o, d, c) : isect_brute(s, o, d, c);
+    Hit h = mode == ORC_ISECT_REF ? isect_ref(s, o, d, c) : mode == ORC_ISECT_FLAT ? (s.fwidth == 4 ? isect_flat4(s, o, d, c) : isect_flat(s, o, d, c)) : isect_brute(s, o, d, c);
     if (h.tri >= 0) c->hits++;
     return h;
 }
@@ -787,6 +846,12 @@ uint32_t orc_scene_triangle_count(const orc_scene* s) { return (uint32_t)s->triM
 int orc_scene_set_flat_bvh(orc_scene* s, const float* nodes, uint32_t n_nodes, const float* tris, uint32_t n_refs) {
     s->fnodes.assign(nodes, nodes + (size_t)n_nodes * 16);
     s->ftris.assign(tris, tris + (size_t)n_refs * 12);
+    s->fwidth = 2;
+    return 0;
+}
+int orc_scene_set_flat_width(orc_scene* s, uint32_t width) {
+    if (width != 2 && width != 4) return 1;
+    s->fwidth = width;
     return 0;
 }
 
@@ -821,6 +886,15 @@ int orc_check_flat_bvh(const orc_scene* s, char* msg, uint32_t cap) {
             seenNode[cur] = 1;
             const float* N = &s->fnodes[(size_t)cur * 16];
             st.push_back((uint32_t)fbits(N[12])); st.push_back((uint32_t)fbits(N[13]));
+            if (s->fwidth == 4) {
+                st.push_back((uint32_t)fbits(N[14])); st.push_back((uint32_t)fbits(N[15]));
+                const uint32_t eb = (uint32_t)fbits(N[3]);
+                for (int a = 0; a < 3; a++) { uint32_t e = (eb >> (8 * a)) & 0xFFu; if (e < 67 || e > 227) return fail(11, "quantisation exponent out of range"); }
+                for (int i = 0; i < 4; i++) for (int a = 0; a < 3; a++) {
+                    uint32_t lo = ((uint32_t)fbits(N[4 + a]) >> (8 * i)) & 0xFFu, hi = ((uint32_t)fbits(N[7 + a]) >> (8 * i)) & 0xFFu;
+                    if ((uint32_t)fbits(N[12 + i]) != 0x80000000u && lo > hi) return fail(12, "inverted quantised child box");
+                }
+            }
         }
     }
     for (size_t t = 0; t < nt; t++) if (!seenTri[t]) return fail(9, "triangle " + std::to_string(t) + " not referenced");

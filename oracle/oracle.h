@@ -96,6 +96,8 @@ void       orc_scene_destroy(orc_scene*);
 uint32_t   orc_scene_triangle_count(const orc_scene*);
 /* product BVH: nodes = n_nodes*16 floats, tris = n_refs*12 floats (layout: include/mipt.h) */
 int        orc_scene_set_flat_bvh(orc_scene*, const float* nodes, uint32_t n_nodes, const float* tris, uint32_t n_refs);
+/* node layout of the flat BVH: 2 = fp32 BVH2 nodes (default), 4 = quantised 4-wide nodes (include/mipt.h) */
+int        orc_scene_set_flat_width(orc_scene*, uint32_t width);
 /* structural check of a flat BVH against the scene's triangles; returns 0 if valid, else an error code (message in buf) */
 int        orc_check_flat_bvh(const orc_scene*, char* msg, uint32_t msgcap);
 

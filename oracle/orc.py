@@ -81,6 +81,7 @@ lib.orc_scene_triangle_count.argtypes = [_vp]
 lib.orc_scene_triangle_count.restype = C.c_uint32
 lib.orc_scene_set_flat_bvh.argtypes = [_vp, _vp, C.c_uint32, _vp, C.c_uint32]
 lib.orc_check_flat_bvh.argtypes = [_vp, C.c_char_p, C.c_uint32]
+lib.orc_scene_set_flat_width.argtypes = [_vp, C.c_uint32]
 lib.orc_trace_rays.argtypes = [_vp, C.c_int, _vp, _vp, C.c_uint32, _vp, C.POINTER(Stats), C.c_int]
 lib.orc_render.argtypes = [_vp, C.POINTER(Settings), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(Stats), C.c_int]
@@ -160,10 +161,13 @@ class Scene:
             d.envH, d.envW = data.env.shape[0], data.env.shape[1]
         self.h = lib.orc_scene_create(C.byref(d))
 
-    def set_flat_bvh(self, nodes, refs):
+    def set_flat_bvh(self, nodes, refs, width=2):
+        """width: node layout of `nodes` (2 = BVH2, 4 = the product's quantised 4-wide nodes)."""
         nodes = np.ascontiguousarray(nodes, np.float32)
         refs = np.ascontiguousarray(refs, np.float32)
         lib.orc_scene_set_flat_bvh(self.h, _ptr(nodes), len(nodes), _ptr(refs), len(refs))
+        if lib.orc_scene_set_flat_width(self.h, width) != 0:
+            raise ValueError("width must be 2 or 4")
 
     def check_flat_bvh(self):
         buf = C.create_string_buffer(256)

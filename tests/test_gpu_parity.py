@@ -47,14 +47,16 @@ def test_device_math_bit_exact(tracer, oracle):
         assert np.array_equal(g.view(np.uint32), c.view(np.uint32)), fn
 
 
+@pytest.mark.parametrize("width", [2, 4], ids=["bvh2", "q4"])
 @pytest.mark.parametrize("builder", [0, 1])
 @pytest.mark.parametrize("scene", ["cornell", "default", "soup"])
-def test_closest_hit_bit_exact(tracer, ptlib, oracle, builder, scene):
+def test_closest_hit_bit_exact(tracer, ptlib, oracle, builder, scene, width):
     data = {"cornell": lambda: ptlib.builtin_scene(0), "default": lambda: ptlib.builtin_scene(1),
             "soup": lambda: soup_scene(20000, 5)}[scene]()
-    sc = ptlib.Scene(tracer, data, builder=builder)
+    sc = ptlib.Scene(tracer, data, builder=builder, node_width=width)
+    assert sc.bvh_width == width
     o = oracle.Scene(data)
-    o.set_flat_bvh(*sc.bvh())
+    o.set_flat_bvh(*sc.bvh(), width)
     og, dg = random_rays(300000, 17)
     g = tracer.trace_rays(sc, og, dg)
     c, _ = o.trace_rays(oracle.ISECT_FLAT, og, dg, nthreads=16)
@@ -98,14 +100,14 @@ def test_golden_render_crop(tracer, ptlib, oracle, name):
     assert np.abs(l[y0:y1, x0:x1].astype(int) - g["ldr"].astype(int)).max() <= 1
 
 
-@pytest.mark.parametrize("integrator", [0, 1], ids=["wavestack", "levelqueues"])
+@pytest.mark.parametrize("integrator,width", [(0, 2), (1, 2), (0, 4), (1, 4)], ids=["wavestack", "levelqueues", "wavestack-q4", "levelqueues-q4"])
 @pytest.mark.parametrize("name,w,h,depth", [("cornell", 160, 96, 5), ("default", 128, 128, 7), ("cornell", 67, 33, 1), ("default", 64, 64, 12)])
-def test_frame_matches_oracle(tracer, ptlib, oracle, name, w, h, depth, integrator):
+def test_frame_matches_oracle(tracer, ptlib, oracle, name, w, h, depth, integrator, width):
     which, cam_kw, env, _, _ = MG.CONFIGS[name]
     data = MG.scene_data(name)
-    sc = ptlib.Scene(tracer, data)
+    sc = ptlib.Scene(tracer, data, node_width=width)
     o = oracle.Scene(data)
-    o.set_flat_bvh(*sc.bvh())
+    o.set_flat_bvh(*sc.bvh(), width)
     s = ptlib.make_settings(ptlib.make_camera(**cam_kw), w, h, depth)
     acc, ldr = dev_buffers(tracer, w, h)
     tracer.set_option("count_pixel_rays", 1)
@@ -303,16 +305,16 @@ def test_device_buffer_layer(tracer, ptlib):
     lib.mipt_buffer_destroy(b2)
 
 
-@pytest.mark.parametrize("name,w,h,depth", [("cornell", 128, 80, 4), ("default", 96, 96, 8), ("cornell", 64, 48, 8)])
-def test_dfs_order_integrator_is_bit_identical_to_the_oracle(tracer, ptlib, oracle, name, w, h, depth):
+@pytest.mark.parametrize("name,w,h,depth,width", [("cornell", 128, 80, 4, 2), ("default", 96, 96, 8, 2), ("cornell", 64, 48, 8, 2), ("default", 96, 96, 8, 4)])
+def test_dfs_order_integrator_is_bit_identical_to_the_oracle(tracer, ptlib, oracle, name, w, h, depth, width):
     """rng_mode = dfs: the reference's single LCG stream per pixel-sample in its depth-first order and its bottom-up
     radiance arithmetic.  No atomics are involved, so the sample, the accumulation buffer and the LDR bytes must equal
     the oracle's DFS mode (same flat BVH, portable math) bit for bit."""
     which, cam_kw, env, _, _ = MG.CONFIGS[name]
     data = MG.scene_data(name)
-    sc = ptlib.Scene(tracer, data)
+    sc = ptlib.Scene(tracer, data, node_width=width)
     o = oracle.Scene(data)
-    o.set_flat_bvh(*sc.bvh())
+    o.set_flat_bvh(*sc.bvh(), width)
     s = ptlib.make_settings(ptlib.make_camera(**cam_kw), w, h, depth)
     acc, ldr = dev_buffers(tracer, w, h)
     tracer.set_option("rng_mode", ptlib.RNG_DFS)
