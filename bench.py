@@ -182,7 +182,7 @@ def main():
     if rank == 0:
         nn, nr = (len(x) for x in sc.bvh())
         if a.integrator == 0:    # one k_wavestack launch per frame traces every ray of the frame
-            kernel_name = "mipt::k_wavestack<%s>" % ("false, true" if sc.bvh_width == 4 else "true, false" if nn * 4 + nr * 3 <= 1024 else "false, false")   # <LDS scene, 4-wide>
+            kernel_name = "mipt::k_wavestack<%s>" % ("false, true" if sc.bvh_width == 4 else "true, false" if nn * 4 + nr * 3 <= 256 else "false, false")   # <LDS scene, 4-wide>
             sec_rays, sec_ms, sec_launches = float(cnt.rays), prof.ms[0], prof.launches[0]
         else:                    # k_level<false,*> launches carry the non-primary levels
             kernel_name = "mipt::k_level<false,*>"

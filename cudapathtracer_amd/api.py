@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmipt.so")
+LIB_PATH = os.environ.get("MIPT_LIB") or os.path.join(_HERE, "libmipt.so")     # MIPT_LIB: an instrumented build (make prof)
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: build it with `make -C cudapathtracer_amd/csrc` (or __graft_entry__.build()); "
@@ -281,6 +281,11 @@ class Scene:
         refs = np.zeros((nr.value, 12), np.float32)
         lib.mipt_scene_get_bvh(self.h, _ptr(nodes), C.byref(nn), _ptr(refs), C.byref(nr))
         return nodes, refs
+
+    def flat(self):
+        """(nodes, refs, width): what the oracle's set_flat_bvh takes."""
+        nodes, refs = self.bvh()
+        return nodes, refs, self.bvh_width
 
     def close(self):
         if self.h:

@@ -32,6 +32,7 @@ struct mipt_tracer {
     int64_t countPixelRays = 0;
     int64_t blocksPerCU = 4;         // resident 256-thread blocks per CU of the persistent kernels
     int64_t refillLanes = 8;
+    int64_t minDescend = 0;
     int64_t profileLevels = 0;
     int64_t integrator = 0;          // 0 persistent wave stacks, 1 level-synchronous queues
     // work buffers
@@ -140,15 +141,15 @@ uint64_t bvh_cache_key(const std::vector<TriPos>& tris, const BvhParams& bp) {
 bool load_bvh_cache(const char* path, uint64_t key, uint32_t nTris, uint32_t width, BvhOut& bo) {
     FILE* f = fopen(path, "rb");
     if (!f) return false;
-    BvhCacheHeader h;
-    bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "MIPTBVH1", 8) && h.key == key && h.nTris == nTris && h.width == width &&
+    BvhCacheHeader h{};
+    bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "MIPTBVH1", 8) && h.key == key && h.nTris == nTris && (width ? h.width == width : (h.width == 2 || h.width == 4)) &&
               h.nNodes > 0 && h.nNodes < (1u << 27) && h.nRefs < (1u << 27);
     if (ok) {
         bo.nodes.resize((size_t)h.nNodes * 16); bo.refTri.resize(h.nRefs);
         ok = fread(bo.nodes.data(), 64, h.nNodes, f) == h.nNodes && (h.nRefs == 0 || fread(bo.refTri.data(), 4, h.nRefs, f) == h.nRefs);
     }
     fclose(f);
-    bo.width = width;
+    bo.width = h.width;
     return ok && validate_bvh(bo, nTris).empty();
 }
 bool save_bvh_cache(const char* path, uint64_t key, uint32_t nTris, const BvhOut& bo) {
@@ -232,6 +233,7 @@ int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
     else if (k == "rng_mode") { if (v != MIPT_RNG_NODE && v != MIPT_RNG_DFS) return fail(t, MIPT_E_INVALID, "bad rng_mode"); t->rngMode = v; }
     else if (k == "count_pixel_rays") t->countPixelRays = v ? 1 : 0;
     else if (k == "refill_lanes") { if (v < 1 || v > 64) return fail(t, MIPT_E_INVALID, "refill_lanes out of range"); t->refillLanes = v; }
+    else if (k == "min_descend_lanes") { if (v < 0 || v > 64) return fail(t, MIPT_E_INVALID, "min_descend_lanes out of range"); t->minDescend = v; }
     else if (k == "profile_levels") t->profileLevels = v ? 1 : 0;
     else if (k == "integrator") { if (v != 0 && v != 1) return fail(t, MIPT_E_INVALID, "integrator must be 0 (wave stacks) or 1 (level queues)"); t->integrator = v; }
     else if (k == "blocks_per_cu") { if (v < 1 || v > 32) return fail(t, MIPT_E_INVALID, "blocks_per_cu out of range"); t->blocksPerCU = v; }
@@ -308,8 +310,8 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
     if (d->maxLeafSize) bp.maxLeafSize = d->maxLeafSize;
     if (d->splitAlpha > 0.f) bp.splitAlpha = d->splitAlpha;
     if (d->sahTriCost > 0.f) bp.triCost = d->sahTriCost;
-    if (d->nodeWidth) bp.nodeWidth = d->nodeWidth;
-    if (bp.nodeWidth != 2 && bp.nodeWidth != 4) return fail(t, MIPT_E_INVALID, "nodeWidth must be 0, 2 or 4");
+    bp.nodeWidth = d->nodeWidth;
+    if (bp.nodeWidth != 0 && bp.nodeWidth != 2 && bp.nodeWidth != 4) return fail(t, MIPT_E_INVALID, "nodeWidth must be 0, 2 or 4");
     BvhOut bo;
     const bool useCache = d->bvhCachePath && d->bvhCachePath[0];
     const uint64_t cacheKey = useCache ? bvh_cache_key(tris, bp) : 0;
@@ -469,7 +471,8 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
         } else if (t->integrator == 0 && D >= 1) {
             HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), t->stream));
             StackArgs SA;
-            SA.S = sc->dev; SA.F = A.F; SA.stack = t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes; SA.pixCounter = t->counts;
+            SA.S = sc->dev; SA.F = A.F; SA.stack = t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes; // auto: 8 for an LDS-resident scene, 24 otherwise (measured optima, profiles/r1/exp_min_descend.log)
+            SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (!sc->dev.wide && sc->dev.nNodes * 4 + sc->dev.nRefs * 3 <= 256 ? 8 : 24)); SA.pixCounter = t->counts;
             SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npix;
             mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
             if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, t->stream)); }

@@ -460,17 +460,23 @@ std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOu
     if (const char* e = std::getenv("MIPT_BUILD_THREADS")) threads = std::atoi(e);
     threads = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
     g_spare.store(threads - 1);
-    if (p.nodeWidth != 2 && p.nodeWidth != 4) return "nodeWidth must be 2 or 4";
+    if (p.nodeWidth != 0 && p.nodeWidth != 2 && p.nodeWidth != 4) return "nodeWidth must be 0 (auto), 2 or 4";
     Builder b(tris, p, out);
     std::string err = b.run();
     if (!err.empty()) return err;
     out.width = 2; out.stackNeed = out.maxDepth + 2;
-    if (p.nodeWidth == 4) {
+    // auto: a scene whose BVH2 + references fit the kernels' 4 KiB LDS window is traversed from LDS as BVH2 (VALU-bound,
+    // measured faster); anything larger lives in L2/HBM, where the 4-wide nodes halve the dependent fetches
+    const bool fitsLds = out.nodes.size() / 16 * 4 + out.refTri.size() * 3 <= kLdsSceneFloat4;
+    if (p.nodeWidth == 4 || (p.nodeWidth == 0 && !fitsLds)) {
         std::vector<float> wide;
         wide.reserve(out.nodes.size() / 2);
         Collapser c(out.nodes, wide);
         const uint32_t need = c.build(0, 0) + 1;                 // + the sentinel
-        if (need > kMaxWideStack) return "4-wide BVH needs a deeper traversal stack than the device has (use nodeWidth 2)";
+        if (need > kMaxWideStack) {
+            if (p.nodeWidth == 0) return "";                     // auto: stay with the BVH2
+            return "4-wide BVH needs a deeper traversal stack than the device has (use nodeWidth 2)";
+        }
         out.nodes.swap(wide);
         out.width = 4; out.maxDepth = c.maxDepth; out.stackNeed = need;
     }

@@ -32,7 +32,7 @@ struct BvhParams {
     float    nodeCost = 1.0f;    // getNodeCost(n) = nodeCost * n
     float    triCost = 1.5f;     // getTriangleCost(n) = triCost * n
     uint32_t minLeafSize = 1;
-    uint32_t nodeWidth = 2;      // 2: fp32 BVH2 nodes, 4: quantised 4-wide nodes
+    uint32_t nodeWidth = 0;      // 2: fp32 BVH2 nodes, 4: quantised 4-wide nodes, 0: BVH2 if the scene fits the LDS window, else 4
 };
 
 struct BvhOut {
@@ -45,6 +45,7 @@ struct BvhOut {
 };
 
 constexpr uint32_t kMaxBvhDepth = 64;       // traversal stack capacity on the device
+constexpr uint32_t kLdsSceneFloat4 = 256;   // float4 slots of the kernels' LDS scene window (kernels.hip kLdsSceneVec)
 constexpr uint32_t kMaxWideStack = 96;      // traversal stack capacity of the 4-wide kernels
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kEmptyRef = 0x80000000u; // 4-wide nodes: "no child" (a leaf of zero references)

@@ -467,6 +467,18 @@ MIPT_DEV void load_ref(const float4* lds, const float4* glb, uint32_t i, float4&
     else { const float4* T = glb + (size_t)i * 3; a = T[0]; b = T[1]; c = T[2]; }
 }
 
+// Lane-utilisation instrumentation (make prof -> libmipt_prof.so, scripts/lane_profile.py).  Wave-level sums land in
+// stats[8..]: [8] traversal rounds, [9] lanes active at round start, [10] node-loop wave iterations (max over lanes),
+// [11] node visits (sum over lanes), [12] leaf-loop wave iterations, [13] triangle tests, [14] full shade batches,
+// [15] lanes in them, [16] terminal batches, [17] lanes in them, [18] refills, [19] lanes refilled.
+#ifdef MIPT_LANE_PROFILE
+#define MIPT_PROF(x) x
+MIPT_DEV uint32_t wave_max_u32(uint32_t v) { for (int s = 32; s > 0; s >>= 1) { uint32_t o = __shfl_xor(v, s); v = o > v ? o : v; } return v; }
+MIPT_DEV uint32_t wave_sum_u32(uint32_t v) { for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s); return v; }
+#else
+#define MIPT_PROF(x)
+#endif
+
 template <bool LDS_SCENE, bool WIDE>
 __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     constexpr int kSqCap = SqCap<LDS_SCENE>::value;
@@ -508,6 +520,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     uint32_t deep[(WIDE ? kWideStackCap : kStackCap) - kLdsStack];
     int tsp = 0;
     uint32_t traced = 0;
+    MIPT_PROF(unsigned long long pf[12] = {};)
 
     while (true) {
         const unsigned long long actMask = __ballot(active);
@@ -519,6 +532,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
         if (nF >= 64u || (nF > 0u && (starving || (pressure && nF >= nT)))) {
             const uint32_t n = nF < 64u ? nF : 64u;
             nF -= n;
+            MIPT_PROF(pf[6]++; pf[7] += n;)
             const bool has = lane < n;
             Bounce b;
             uint32_t spix = 0, snode = 0, ss0 = 0;
@@ -563,6 +577,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
         // ---- A2. a batch of terminal records: miss radiance, or the emission of a hit at the last level -------------
         if (nT >= 64u || (nT > 0u && (starving || pressure))) {
             const uint32_t n = nT < 64u ? nT : 64u;
+            MIPT_PROF(pf[8]++; pf[9] += n;)
             if (lane < n) {
                 const uint32_t e = (uint32_t)kSqCap - nT + lane;
                 v3 sd = mk3(sq[3 * kSqCap + e], sq[4 * kSqCap + e], sq[5 * kSqCap + e]);
@@ -593,6 +608,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 if (got < want) more = false;
             }
             sp -= take;
+            MIPT_PROF(pf[10]++; pf[11] += take + got;)
             if (!active) {
                 const uint32_t rank = (uint32_t)__popcll(~actMask & below);
                 if (rank < got + take) {
@@ -617,14 +633,27 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
         }
 
         // ---- C. done when nothing is in flight, parked, stacked or left in the frame --------------------------------
-        if (!__ballot(active)) {
+        const uint32_t nActive = (uint32_t)__popcll(__ballot(active));
+        if (nActive == 0u) {
             if (nF + nT == 0u) break;
             continue;
         }
 
         // ---- D. one traversal round: descend to the next leaf, test it, park the rays that have terminated ----------
-        if (active) {
-            while (!(cur & kLeaf)) {
+        MIPT_PROF(uint32_t myNodes = 0; uint32_t myTris = 0;)
+        // The node loop is wave-uniform: every lane stays in it and the visit runs under `go`.  It ends when fewer than
+        // minDescend lanes are still at inner nodes -- those resume next round, after the others' leaves have been
+        // tested and terminated rays replaced -- which bounds the tail of the loop (profiles/r1/lane_profile_*.log).
+        // minDescend = 1 is the classic while-while.
+        const uint32_t minDescend = A.minDescend < (nActive + 1u) / 2u ? A.minDescend : (nActive + 1u) / 2u;   // thin waves: scale down
+        bool firstVisit = true;                 // every round makes progress: the first visit is unconditional
+        while (true) {
+            const bool go = active && !(cur & kLeaf);
+            const uint32_t nGo = (uint32_t)__popcll(__ballot(go));
+            if (nGo == 0u || (!firstVisit && nGo < minDescend)) break;
+            firstVisit = false;
+            if (go) {
+                MIPT_PROF(myNodes++;)
                 float4 n0, n1, n2, n3;
                 load_node<LDS_SCENE>(ldsNodes, A.S.nodes, cur, n0, n1, n2, n3);
                 if constexpr (WIDE) {
@@ -637,26 +666,29 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                         if (nh > 1) MIPT_STACK_PUSH(lstk, deep, tsp, s1_);
                         cur = s0_;
                     }
-                    continue;
-                }
-                float t0, t1;
-                bool h0 = slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, h.t, t0);
-                bool h1 = slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, h.t, t1);
-                uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
-                if (h0 || h1) {
-                    uint32_t first = h0 ? c0 : c1;
-                    if (h0 && h1) {
-                        uint32_t second = c1;
-                        if (t1 < t0) { first = c1; second = c0; }
-                        MIPT_STACK_PUSH(lstk, deep, tsp, second);
-                    }
-                    cur = first;
                 } else {
-                    MIPT_STACK_POP(lstk, deep, tsp, cur);
+                    float t0, t1;
+                    bool h0 = slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, h.t, t0);
+                    bool h1 = slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, h.t, t1);
+                    uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
+                    if (h0 || h1) {
+                        uint32_t first = h0 ? c0 : c1;
+                        if (h0 && h1) {
+                            uint32_t second = c1;
+                            if (t1 < t0) { first = c1; second = c0; }
+                            MIPT_STACK_PUSH(lstk, deep, tsp, second);
+                        }
+                        cur = first;
+                    } else {
+                        MIPT_STACK_POP(lstk, deep, tsp, cur);
+                    }
                 }
             }
-            if (cur != kTerm) {
+        }
+        if (active) {
+            if ((cur & kLeaf) && cur != kTerm) {
                 uint32_t cnt = (cur >> 27) & 0xFu, first = cur & 0x07FFFFFFu;
+                MIPT_PROF(myTris = cnt;)
                 for (uint32_t i = first; i < first + cnt; i++) {
                     float4 a, b, c;
                     load_ref<LDS_SCENE>(ldsRefs, A.S.refs, i, a, b, c);
@@ -667,6 +699,8 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 MIPT_STACK_POP(lstk, deep, tsp, cur);
             }
         }
+        MIPT_PROF(pf[0]++; pf[1] += (uint32_t)__popcll(__ballot(active)); pf[2] += wave_max_u32(myNodes); pf[3] += wave_sum_u32(myNodes);
+                  pf[4] += wave_max_u32(myTris); pf[5] += wave_sum_u32(myTris);)
         bool fin = active && cur == kTerm;
         unsigned long long fm = __ballot(fin);
         if (fm) {
@@ -692,6 +726,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     // one counter update per wave
     for (int sh = 32; sh > 0; sh >>= 1) traced += __shfl_down(traced, sh);
     if (lane == 0 && traced) atomicAdd(A.stats, (unsigned long long)traced);
+    MIPT_PROF(if (lane == 0) for (int k = 0; k < 12; k++) atomicAdd(A.stats + 8 + k, pf[k]);)
 }
 
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {

@@ -28,7 +28,7 @@ for which, cam_kw, depth in ((0, pt.CORNELL_CAMERA, 4), (1, pt.DEFAULT_CAMERA, 4
     sc = pt.Scene(t, data)
     nodes, refs = sc.bvh()
     o = orc.Scene(data)
-    o.set_flat_bvh(nodes, refs)
+    o.set_flat_bvh(nodes, refs, sc.bvh_width)
     print("scene", which, "nodes", len(nodes), "refs", len(refs), "check", o.check_flat_bvh())
     N = 200000
     org = rng.uniform(-3, 3, (N, 3)).astype(np.float32)

@@ -21,7 +21,7 @@ c = t.counters()
 print(f"grid {n}: {dt/frames*1e3:.2f} ms/frame, {c.rays/frames/1e6:.1f} Mrays/frame, {c.rays/dt/1e6:.0f} Mrays/s", flush=True)
 if len(sys.argv) > 3:   # oracle sample for N_node / N_tri
     from oracle import orc
-    o = orc.Scene(data); o.set_flat_bvh(nodes, refs)
+    o = orc.Scene(data); o.set_flat_bvh(nodes, refs, sc.bvh_width)
     st_tot = [0, 0, 0]
     for y in range(0, H, H // 8):
         r = o.render(s, orc.ISECT_FLAT, orc.RNG_NODE, orc.MATH_DET, 1, 1, rect=(0, y, W, y + 1), want_ldr=False, nthreads=16)

@@ -56,7 +56,7 @@ def test_closest_hit_bit_exact(tracer, ptlib, oracle, builder, scene, width):
     sc = ptlib.Scene(tracer, data, builder=builder, node_width=width)
     assert sc.bvh_width == width
     o = oracle.Scene(data)
-    o.set_flat_bvh(*sc.bvh(), width)
+    o.set_flat_bvh(*sc.flat())
     og, dg = random_rays(300000, 17)
     g = tracer.trace_rays(sc, og, dg)
     c, _ = o.trace_rays(oracle.ISECT_FLAT, og, dg, nthreads=16)
@@ -107,7 +107,7 @@ def test_frame_matches_oracle(tracer, ptlib, oracle, name, w, h, depth, integrat
     data = MG.scene_data(name)
     sc = ptlib.Scene(tracer, data, node_width=width)
     o = oracle.Scene(data)
-    o.set_flat_bvh(*sc.bvh(), width)
+    o.set_flat_bvh(*sc.flat())
     s = ptlib.make_settings(ptlib.make_camera(**cam_kw), w, h, depth)
     acc, ldr = dev_buffers(tracer, w, h)
     tracer.set_option("count_pixel_rays", 1)
@@ -144,7 +144,7 @@ def test_env_map_lookup(tracer, ptlib, oracle):
     data = ptlib.SceneData([(v, np.arange(3, dtype=np.uint32), ptlib.make_material())], sky, env)
     sc = ptlib.Scene(tracer, data)
     o = oracle.Scene(data)
-    o.set_flat_bvh(*sc.bvh())
+    o.set_flat_bvh(*sc.flat())
     for zen in (0.0, 1.3, float(np.float32(np.pi))):
         cam = ptlib.make_camera((0, 0, 0), 2.0, zen, 1.0)
         s = ptlib.make_settings(cam, 96, 64, 3)
@@ -224,7 +224,7 @@ def test_full_size_properties_1080p(tracer, ptlib, oracle):
         assert l[..., :3].max() <= 186 and (l[..., 3] == 255).all()
         # oracle spot check on three rows of the full-size frame
         o = oracle.Scene(data)
-        o.set_flat_bvh(*sc.bvh())
+        o.set_flat_bvh(*sc.flat())
         rgb = rgb.reshape(h, w, 3)
         for y in (0, 517, 1079):
             r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 2, 1, rect=(0, y, w, y + 1), nthreads=16)
@@ -314,7 +314,7 @@ def test_dfs_order_integrator_is_bit_identical_to_the_oracle(tracer, ptlib, orac
     data = MG.scene_data(name)
     sc = ptlib.Scene(tracer, data, node_width=width)
     o = oracle.Scene(data)
-    o.set_flat_bvh(*sc.bvh(), width)
+    o.set_flat_bvh(*sc.flat())
     s = ptlib.make_settings(ptlib.make_camera(**cam_kw), w, h, depth)
     acc, ldr = dev_buffers(tracer, w, h)
     tracer.set_option("rng_mode", ptlib.RNG_DFS)

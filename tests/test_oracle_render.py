@@ -51,8 +51,7 @@ def test_golden_rays_regression(oracle, name):
 def test_intersector_backends_give_the_same_image(ptlib, oracle):
     data = MG.scene_data("cornell")
     o = oracle.Scene(data)
-    nodes, refs = ptlib.Scene(None, data).bvh()
-    o.set_flat_bvh(nodes, refs)
+    o.set_flat_bvh(*ptlib.Scene(None, data).flat())
     s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), 96, 96, 4)
     imgs = [o.render(s, m, oracle.RNG_DFS, oracle.MATH_LIBM, 0, 2) for m in (oracle.ISECT_REF, oracle.ISECT_FLAT, oracle.ISECT_BRUTE)]
     for r in imgs[1:]:

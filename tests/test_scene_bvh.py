@@ -53,20 +53,29 @@ def decode(ref):
 
 @pytest.mark.parametrize("builder", [0, 1])
 @pytest.mark.parametrize("scene", ["cornell", "default", "soup"])
-def test_flat_bvh_valid_and_equal_to_brute_force(ptlib, oracle, builder, scene):
+@pytest.mark.parametrize("width", [2, 4], ids=["bvh2", "q4"])
+def test_flat_bvh_valid_and_equal_to_brute_force(ptlib, oracle, builder, scene, width):
     data = {"cornell": lambda: ptlib.builtin_scene(0), "default": lambda: ptlib.builtin_scene(1),
             "soup": lambda: soup_scene(10000, 5)}[scene]()
-    sc = ptlib.Scene(None, data, builder=builder)
+    sc = ptlib.Scene(None, data, builder=builder, node_width=width)
     nodes, refs = sc.bvh()
-    assert len(refs) >= data.triangle_count
+    assert sc.bvh_width == width and len(refs) >= data.triangle_count
+    # auto layout: BVH2 when nodes + references fit the kernels' 4 KiB LDS window (the Cornell box), else 4-wide
+    assert ptlib.Scene(None, data, builder=builder).bvh_width == (2 if scene == "cornell" else 4)
     o = oracle.Scene(data)
-    o.set_flat_bvh(nodes, refs)
+    o.set_flat_bvh(nodes, refs, width)
     assert o.check_flat_bvh() == (0, "")
     # leaf sizes respect the default maximum of 4; children boxes are well formed
-    kids = nodes[:, 12:14].view(np.uint32)
+    kids = nodes[:, 12:12 + width].view(np.uint32)
     leaf = (kids & 0x80000000) != 0
     assert (((kids >> 27) & 0xF)[leaf] <= 4).all()
-    assert (nodes[:, 0:3] <= nodes[:, 3:6]).all() and (nodes[:, 6:9] <= nodes[:, 9:12]).all()
+    if width == 2:
+        assert (nodes[:, 0:3] <= nodes[:, 3:6]).all() and (nodes[:, 6:9] <= nodes[:, 9:12]).all()
+    else:
+        q = nodes[:, 4:10].view(np.uint8).reshape(-1, 6, 4)                  # [node][qlo xyz, qhi xyz][child]
+        used = (kids != 0x80000000)
+        assert ((q[:, 0:3, :] <= q[:, 3:6, :]) | ~used[:, None, :]).all()
+        assert len(nodes) < len(ptlib.Scene(None, data, builder=builder, node_width=2).bvh()[0])
     og, dg = random_rays(20000, 21)
     a, st = o.trace_rays(oracle.ISECT_FLAT, og, dg)
     b, _ = o.trace_rays(oracle.ISECT_BRUTE, og, dg)
@@ -88,7 +97,7 @@ def test_sbvh_spatial_splits_duplicate_references(ptlib, oracle):
     v["position"] = np.concatenate([ground, small]).astype(np.float32).reshape(-1, 3)
     v["normal"] = (0, 1, 0)
     data = ptlib.SceneData([(v, np.arange(3 * n, dtype=np.uint32), ptlib.make_material())], ptlib.SkyLight())
-    nodes, refs = ptlib.Scene(None, data).bvh()
+    nodes, refs = ptlib.Scene(None, data, node_width=2).bvh()
     assert len(refs) > n
     o = oracle.Scene(data)
     o.set_flat_bvh(nodes, refs)
@@ -99,7 +108,7 @@ def test_sbvh_spatial_splits_duplicate_references(ptlib, oracle):
     b, _ = o.trace_rays(oracle.ISECT_BRUTE, og, dg)
     assert ((f["tri"] != b["tri"]) | (f["t"] != b["t"])).sum() <= 10
     # and it pays: fewer triangle tests than the median tree on the same rays
-    n2, r2 = ptlib.Scene(None, data, builder=1).bvh()
+    n2, r2 = ptlib.Scene(None, data, builder=1, node_width=2).bvh()
     o.set_flat_bvh(n2, r2)
     _, sm = o.trace_rays(oracle.ISECT_FLAT, og, dg)
     assert sf.tri_tests < sm.tri_tests
@@ -110,11 +119,11 @@ def test_tiny_scenes(ptlib, oracle, ntri):
     data = soup_scene(max(ntri, 1), 9)
     if ntri == 0:
         data = ptlib.SceneData([], data.sky)
-    for builder in (0, 1):
-        nodes, refs = ptlib.Scene(None, data, builder=builder).bvh()
-        assert len(nodes) >= 1 and len(refs) == ntri
+    for builder, width in ((0, 2), (1, 2), (0, 4), (1, 4), (0, 0)):
+        nodes, refs, w = ptlib.Scene(None, data, builder=builder, node_width=width).flat()
+        assert len(nodes) >= 1 and len(refs) == ntri and w == (width or 2)
         o = oracle.Scene(data)
-        o.set_flat_bvh(nodes, refs)
+        o.set_flat_bvh(nodes, refs, w)
         assert o.check_flat_bvh()[0] == 0
         og, dg = random_rays(2000, 1, -5, 5)
         f, _ = o.trace_rays(oracle.ISECT_FLAT, og, dg)
@@ -131,10 +140,10 @@ def test_degenerate_and_duplicate_triangles(ptlib, oracle):
     v["position"] = pos.reshape(-1, 3)
     v["normal"] = (0, 1, 0)
     data = ptlib.SceneData([(v, np.arange(120, dtype=np.uint32), ptlib.make_material())], ptlib.SkyLight())
-    for builder in (0, 1):
-        nodes, refs = ptlib.Scene(None, data, builder=builder).bvh()
+    for builder, width in ((0, 2), (1, 2), (0, 4), (1, 4)):
+        nodes, refs, w = ptlib.Scene(None, data, builder=builder, node_width=width).flat()
         o = oracle.Scene(data)
-        o.set_flat_bvh(nodes, refs)
+        o.set_flat_bvh(nodes, refs, w)
         assert o.check_flat_bvh()[0] == 0
         h, _ = o.trace_rays(oracle.ISECT_FLAT, np.array([(0.25, 1, 0.5)], np.float32), np.array([(0, -1, 0)], np.float32))
         assert h["tri"][0] == 0 and h["t"][0] == 1.0        # lowest id wins the 20-way tie
@@ -161,13 +170,14 @@ def test_parallel_build_is_thread_count_independent(ptlib, oracle, monkeypatch):
     out = []
     for threads in ("1", "2", "7"):
         monkeypatch.setenv("MIPT_BUILD_THREADS", threads)
-        nodes, refs = ptlib.Scene(None, data).bvh()
+        nodes, refs, width = ptlib.Scene(None, data).flat()
+        assert width == 4
         out.append((nodes.copy(), refs.copy()))
     for nodes, refs in out[1:]:
         assert np.array_equal(nodes.view(np.uint32), out[0][0].view(np.uint32)) and np.array_equal(refs, out[0][1])
     nodes, refs = out[0]
     o = oracle.Scene(data)
-    o.set_flat_bvh(nodes, refs)
+    o.set_flat_bvh(nodes, refs, 4)
     assert o.check_flat_bvh() == (0, "")
     og, dg = random_rays(20000, 33, -6, 6)
     og[:, 1] = 2 + np.abs(og[:, 1]) * 0.3
