@@ -379,6 +379,7 @@ class Collapser {
 public:
     Collapser(const std::vector<float>& n2, std::vector<float>& n4) : N2(n2), N4(n4) {}
     uint32_t maxDepth = 0;
+    bool failed = false;
     // returns the worst-case number of stack entries below (and including the pushes of) this node
     uint32_t build(uint32_t node2, uint32_t level) {
         maxDepth = std::max(maxDepth, level);
@@ -421,11 +422,11 @@ private:
         uint32_t e[3]; uint8_t qlo[3][4] = {}, qhi[3][4] = {};
         for (int a = 0; a < 3; a++) {
             const float origin = nb.mn[a];
-            // smallest power of two with 255 * scale >= extent; kept inside [2^-60, 2^100] so no product with a ray's
-            // inverse direction (<= 2^80) leaves the normal range
+            // smallest power of two with 255 * scale >= extent; kept inside [2^-60, 2^40] so the product with a ray's
+            // inverse direction (1 <= |idir| <= 2^80) stays a normal, finite number
             int ex = 127 - 60;
             const float ext = nb.mx[a] - origin;
-            while (ex < 227 && 255.0f * scale_of((uint32_t)ex) < ext) ex++;
+            while (ex < 167 && 255.0f * scale_of((uint32_t)ex) < ext) ex++;
             for (;; ex++) {      // widen until every child plane fits (fp32 rounding of the extent can cost one step)
                 bool ok = true;
                 const float sc = scale_of((uint32_t)ex);
@@ -438,7 +439,8 @@ private:
                     if (hi > 255 || std::fma((float)lo, sc, origin) > ch[i].b.mn[a]) { ok = false; break; }
                     qlo[a][i] = (uint8_t)lo; qhi[a][i] = (uint8_t)hi;
                 }
-                if (ok || ex >= 227) break;
+                if (ok) break;
+                if (ex >= 167) { failed = true; break; }     // extent beyond 2^48: not representable
             }
             e[a] = (uint32_t)ex;
         }
@@ -473,9 +475,10 @@ std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOu
         wide.reserve(out.nodes.size() / 2);
         Collapser c(out.nodes, wide);
         const uint32_t need = c.build(0, 0) + 1;                 // + the sentinel
-        if (need > kMaxWideStack) {
+        if (need > kMaxWideStack || c.failed) {
             if (p.nodeWidth == 0) return "";                     // auto: stay with the BVH2
-            return "4-wide BVH needs a deeper traversal stack than the device has (use nodeWidth 2)";
+            return c.failed ? "scene extent too large for quantised 4-wide nodes (use nodeWidth 2)"
+                            : "4-wide BVH needs a deeper traversal stack than the device has (use nodeWidth 2)";
         }
         out.nodes.swap(wide);
         out.width = 4; out.maxDepth = c.maxDepth; out.stackNeed = need;
@@ -504,7 +507,7 @@ std::string validate_bvh(BvhOut& out, uint32_t nTris) {
         uint32_t r[4]; memcpy(r, P + 12, 16);
         if (wide) {
             uint32_t eb; memcpy(&eb, P + 3, 4);
-            for (int a = 0; a < 3; a++) { uint32_t e = (eb >> (8 * a)) & 0xFFu; if (e < 67 || e > 227) return "quantisation exponent out of range"; }
+            for (int a = 0; a < 3; a++) { uint32_t e = (eb >> (8 * a)) & 0xFFu; if (e < 67 || e > 167) return "quantisation exponent out of range"; }
             for (int a = 0; a < 3; a++) if (!std::isfinite(P[a])) return "node origin is not finite";
         }
         for (int c = 0; c < fan; c++) {

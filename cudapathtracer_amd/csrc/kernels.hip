@@ -139,6 +139,9 @@ MIPT_DEV int wide_visit(const RayPre& r, float4 n0, float4 n1, float4 n2, float4
     const float iy = r.idir.y * __uint_as_float(((eb >> 8) & 0xFFu) << 23);
     const float iz = r.idir.z * __uint_as_float(((eb >> 16) & 0xFFu) << 23);
     const float ox = (n0.x - r.o.x) * r.idir.x, oy = (n0.y - r.o.y) * r.idir.y, oz = (n0.z - r.o.z) * r.idir.z;
+    // (picking entry / exit planes by the ray's octant -- one select per axis for all four children instead of a
+    // min/max per plane pair -- gives the same values and was measured 5 % slower: the compiler already folds these
+    // into v_min3/v_max3)
     const uint32_t lx = __float_as_uint(n1.x), ly = __float_as_uint(n1.y), lz = __float_as_uint(n1.z);
     const uint32_t hx = __float_as_uint(n1.w), hy = __float_as_uint(n2.x), hz = __float_as_uint(n2.y);
     float t[4]; uint32_t ref[4] = { __float_as_uint(n3.x), __float_as_uint(n3.y), __float_as_uint(n3.z), __float_as_uint(n3.w) };

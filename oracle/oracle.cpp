@@ -889,7 +889,7 @@ int orc_check_flat_bvh(const orc_scene* s, char* msg, uint32_t cap) {
             if (s->fwidth == 4) {
                 st.push_back((uint32_t)fbits(N[14])); st.push_back((uint32_t)fbits(N[15]));
                 const uint32_t eb = (uint32_t)fbits(N[3]);
-                for (int a = 0; a < 3; a++) { uint32_t e = (eb >> (8 * a)) & 0xFFu; if (e < 67 || e > 227) return fail(11, "quantisation exponent out of range"); }
+                for (int a = 0; a < 3; a++) { uint32_t e = (eb >> (8 * a)) & 0xFFu; if (e < 67 || e > 167) return fail(11, "quantisation exponent out of range"); }
                 for (int i = 0; i < 4; i++) for (int a = 0; a < 3; a++) {
                     uint32_t lo = ((uint32_t)fbits(N[4 + a]) >> (8 * i)) & 0xFFu, hi = ((uint32_t)fbits(N[7 + a]) >> (8 * i)) & 0xFFu;
                     if ((uint32_t)fbits(N[12 + i]) != 0x80000000u && lo > hi) return fail(12, "inverted quantised child box");

@@ -2,7 +2,7 @@
 usage: MIPT_LIB=cudapathtracer_amd/libmipt_prof.so python scripts/lane_profile.py cornell|default|grid [node_width] [frames]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 assert "prof" in os.environ.get("MIPT_LIB", ""), "set MIPT_LIB to the instrumented library"
 import cudapathtracer_amd as pt
 wl = sys.argv[1]; nw = int(sys.argv[2]) if len(sys.argv) > 2 else 0; frames = int(sys.argv[3]) if len(sys.argv) > 3 else 2

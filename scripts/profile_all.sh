@@ -10,6 +10,7 @@ OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
+export PYTHONPATH=$R
 for w in "${WL[@]}"; do
   steps=8; [ $w = grid ] && steps=4
   echo "== $w: kernel trace"
@@ -28,4 +29,11 @@ for w in "${WL[@]}"; do
   timeout -k 10 400 python3 $R/bench.py --workload $w --steps $steps --warmup 2 > $OUT/bench_$w.json 2> $OUT/bench_$w.err || { echo "bench failed for $w"; exit 1; }
   tail -c 2500 $OUT/bench_$w.json
 done
+if [ -f $R/cudapathtracer_amd/libmipt_prof.so ]; then
+  for w in "${WL[@]}"; do
+    echo "== $w: lane profile (instrumented build)"
+    MIPT_LIB=$R/cudapathtracer_amd/libmipt_prof.so timeout -k 10 200 python3 $R/scripts/lane_profile.py $w > $OUT/lane_profile_$w.log 2>&1 || { echo "lane profile failed for $w"; exit 1; }
+    cat $OUT/lane_profile_$w.log
+  done
+fi
 echo PROFILE_ALL_DONE
