@@ -43,17 +43,19 @@ def parse():
     p.add_argument("--integrator", type=int, default=0, help="0 persistent wave stacks (default), 1 level-synchronous queues")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (default); gloo = rehearsal of the N>1 flow through host memory")
     p.add_argument("--node-width", type=int, default=0, help="BVH node layout: 0 library default, 2 fp32 BVH2, 4 quantised 4-wide")
+    p.add_argument("--estimator", type=int, default=0, help="0 the reference's estimator (default, the parity configuration); 1 env-map importance sampling with occlusion rays")
     p.add_argument("--traffic-gb", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC run (GB)")
     return p.parse_args()
 
 
-def oracle_sample(pt, data, bvh, width, settings, seconds, threads):
+def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0):
     """Times the CPU oracle (same flat BVH, node-keyed RNG) on evenly spaced rows of frame 0 and returns its rate
     and the mean node visits / triangle tests per non-primary ray (the figures B_ray is computed from)."""
     from oracle import orc                      # cpu_baseline leg only: checker / reported baseline
     import ctypes as C
     o = orc.Scene(data)
     o.set_flat_bvh(*bvh, width)
+    o.set_estimator(estimator)
     W, H = settings.viewportWidth, settings.viewportHeight
 
     def run(rows, depth):
@@ -128,6 +130,7 @@ def main():
     if a.tile_pixels:
         t.set_option("tile_pixels", a.tile_pixels)
     t.set_option("integrator", a.integrator)
+    t.set_option("estimator", a.estimator)
     sc = pt.Scene(t, data, node_width=a.node_width)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     ldr = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
@@ -172,12 +175,12 @@ def main():
     cnt = t.counters()
     prof = t.level_profile()
     cdev = dev if a.backend == "nccl" else torch.device("cpu")
-    rays = torch.tensor([float(cnt.rays)], dtype=torch.float64, device=cdev)
+    rays = torch.tensor([float(cnt.rays), float(cnt.shadow_rays)], dtype=torch.float64, device=cdev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_rays, dt = float(rays.item()), float(tmax.item())
+    total_rays, total_shadow, dt = float(rays[0].item()), float(rays[1].item()), float(tmax.item())
 
     if rank == 0:
         nn, nr = (len(x) for x in sc.bvh())
@@ -193,13 +196,13 @@ def main():
         n_node = n_tri = miss = None
         if a.cpu_seconds > 0:
             threads = min(os.cpu_count() or 1, 16)
-            cpu = oracle_sample(pt, data, sc.bvh(), sc.bvh_width, settings, a.cpu_seconds if world == 1 else min(a.cpu_seconds, 3.0), threads)
+            cpu = oracle_sample(pt, data, sc.bvh(), sc.bvh_width, settings, a.cpu_seconds if world == 1 else min(a.cpu_seconds, 3.0), threads, a.estimator)
             n_node, n_tri, miss = cpu["n_node"], cpu["n_tri"], cpu["miss_frac"]
             if a.integrator == 0:
                 n_node, n_tri, miss = cpu["n_node_all"], cpu["n_tri_all"], cpu["miss_all"]
         traffic = a.traffic_gb
         default_size = (W, H) == ((3840, 2160) if a.workload == "grid" else (1920, 1080)) and (a.workload != "grid" or a.grid_n == 2236)
-        if traffic is None and a.integrator == 0 and default_size and not a.depth and not a.node_width:
+        if traffic is None and a.integrator == 0 and default_size and not a.depth and not a.node_width and not a.estimator:
             # HBM bytes per launch from the committed PMC passes of this same command (scripts/pmc_passes.sh;
             # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, plus WRITE_SIZE)
             try:
@@ -230,7 +233,7 @@ def main():
                        "triangles": data.triangle_count, "bvh": "sbvh" + ("-q4" if sc.bvh_width == 4 else ""), "rng": "node", "integrator": "wave-stacks" if a.integrator == 0 else "level-queues", "parallelism": f"sample-striding x{world}",
                        "env_map": None if data.env is None else "synthetic 2048x1024"},
             "spp_per_s": round(a.steps * world / dt, 3), "rays_per_step_per_gpu": round(total_rays / a.steps / world, 1),
-            "shadow_rays": 0, "kernel_ms_per_step": round(cnt.kernel_ms / a.steps, 3),
+            "shadow_rays": round(total_shadow / a.steps / world, 1), "estimator": "reference" if a.estimator == 0 else "env-map importance sampling", "kernel_ms_per_step": round(cnt.kernel_ms / a.steps, 3),
             "level_ms": [round(prof.ms[k] / a.steps, 3) for k in range(depth)] if a.integrator else None,
             "level_mrays": [round(prof.rays[k] / a.steps / 1e6, 2) for k in range(depth)] if a.integrator else None,
             "accumulate_ms": round(prof.accumulate_ms / a.steps, 3),

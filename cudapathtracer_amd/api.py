@@ -56,7 +56,8 @@ class SceneDesc(C.Structure):
 
 
 class Counters(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("frames", C.c_uint64), ("kernel_ms", C.c_double), ("launches", C.c_uint64)]
+    _fields_ = [("rays", C.c_uint64), ("frames", C.c_uint64), ("kernel_ms", C.c_double), ("launches", C.c_uint64),
+                ("shadow_rays", C.c_uint64)]
 
 
 class LevelProfile(C.Structure):
@@ -88,6 +89,8 @@ lib.mipt_scene_get_bvh.argtypes = [_vp, _vp, C.POINTER(C.c_uint32), _vp, C.POINT
 lib.mipt_scene_triangle_count.argtypes = [_vp]
 lib.mipt_scene_triangle_count.restype = C.c_uint32
 lib.mipt_scene_bvh_was_cached.argtypes = [_vp]
+lib.mipt_scene_get_env_cdf.argtypes = [_vp, _vp, C.c_uint64]
+lib.mipt_scene_get_env_cdf.restype = C.c_uint64
 lib.mipt_scene_bvh_width.argtypes = [_vp]
 lib.mipt_scene_bvh_width.restype = C.c_uint32
 lib.mipt_trace.argtypes = [_vp, _vp, C.POINTER(Settings), _vp, _vp]
@@ -281,6 +284,12 @@ class Scene:
         refs = np.zeros((nr.value, 12), np.float32)
         lib.mipt_scene_get_bvh(self.h, _ptr(nodes), C.byref(nn), _ptr(refs), C.byref(nr))
         return nodes, refs
+
+    def env_cdf(self):
+        n = lib.mipt_scene_get_env_cdf(self.h, None, 0)
+        out = np.zeros(n, np.float32)
+        lib.mipt_scene_get_env_cdf(self.h, _ptr(out), n)
+        return out
 
     def flat(self):
         """(nodes, refs, width): what the oracle's set_flat_bvh takes."""

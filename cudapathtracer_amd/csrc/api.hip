@@ -33,6 +33,7 @@ struct mipt_tracer {
     int64_t blocksPerCU = 4;         // resident 256-thread blocks per CU of the persistent kernels
     int64_t refillLanes = 8;
     int64_t minDescend = 0;
+    int64_t estimator = 0;
     int64_t profileLevels = 0;
     int64_t integrator = 0;          // 0 persistent wave stacks, 1 level-synchronous queues
     // work buffers
@@ -54,7 +55,8 @@ struct mipt_tracer {
 struct mipt_scene {
     mipt_tracer* t = nullptr;
     SceneDev dev = {};
-    void* dNodes = nullptr; void* dRefs = nullptr; void* dShade = nullptr; void* dMats = nullptr; void* dEnv = nullptr;
+    void* dNodes = nullptr; void* dRefs = nullptr; void* dShade = nullptr; void* dMats = nullptr; void* dEnv = nullptr; void* dEnvCdf = nullptr;
+    std::vector<float> hEnvCdf;
     std::vector<float> hNodes, hRefs;    // host copies for mipt_scene_get_bvh
     uint32_t nTris = 0;
     uint32_t bvhWidth = 2;
@@ -152,6 +154,35 @@ bool load_bvh_cache(const char* path, uint64_t key, uint32_t nTris, uint32_t wid
     bo.width = h.width;
     return ok && validate_bvh(bo, nTris).empty();
 }
+// Sampling tables of the env-map importance sampling estimator (option "estimator" = 1): rowCdf[H+1], then H rows of
+// colCdf[W+1].  Specification (include/mipt.h; the test oracle restates it independently): weight(iv,iu) = ((double)r + g + b) *
+// sin(pi (iv + 0.5) / H); per row the running sum over the row total (uniform if the row is black); the marginal
+// likewise over the row totals; all in double, stored as float.
+void build_env_cdf(const float* env, uint32_t W, uint32_t H, std::vector<float>& out) {
+    out.assign((size_t)(H + 1) + (size_t)H * (W + 1), 0.f);
+    float* row = out.data(); float* col = row + (H + 1);
+    std::vector<double> rowTotal(H), acc(W + 1);
+    for (uint32_t iv = 0; iv < H; iv++) {
+        const double sinT = sin(M_PI * ((double)iv + 0.5) / (double)H);
+        acc[0] = 0.0;
+        for (uint32_t iu = 0; iu < W; iu++) {
+            const float* p = env + ((size_t)iv * W + iu) * 3;
+            acc[iu + 1] = acc[iu] + ((double)p[0] + (double)p[1] + (double)p[2]) * sinT;
+        }
+        rowTotal[iv] = acc[W];
+        float* c = col + (size_t)iv * (W + 1);
+        for (uint32_t iu = 0; iu <= W; iu++) c[iu] = acc[W] > 0.0 ? (float)(acc[iu] / acc[W]) : (float)((double)iu / (double)W);
+        c[W] = 1.0f;
+    }
+    double total = 0.0; for (uint32_t iv = 0; iv < H; iv++) total += rowTotal[iv];
+    double run = 0.0;
+    for (uint32_t iv = 0; iv <= H; iv++) {
+        row[iv] = total > 0.0 ? (float)(run / total) : (float)((double)iv / (double)H);
+        if (iv < H) run += rowTotal[iv];
+    }
+    row[H] = 1.0f;
+}
+
 bool save_bvh_cache(const char* path, uint64_t key, uint32_t nTris, const BvhOut& bo) {
     std::string tmp = std::string(path) + ".tmp";
     FILE* f = fopen(tmp.c_str(), "wb");
@@ -234,6 +265,7 @@ int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
     else if (k == "count_pixel_rays") t->countPixelRays = v ? 1 : 0;
     else if (k == "refill_lanes") { if (v < 1 || v > 64) return fail(t, MIPT_E_INVALID, "refill_lanes out of range"); t->refillLanes = v; }
     else if (k == "min_descend_lanes") { if (v < 0 || v > 64) return fail(t, MIPT_E_INVALID, "min_descend_lanes out of range"); t->minDescend = v; }
+    else if (k == "estimator") { if (v != 0 && v != 1) return fail(t, MIPT_E_INVALID, "estimator must be 0 (reference) or 1 (env-map importance sampling)"); t->estimator = v; }
     else if (k == "profile_levels") t->profileLevels = v ? 1 : 0;
     else if (k == "integrator") { if (v != 0 && v != 1) return fail(t, MIPT_E_INVALID, "integrator must be 0 (wave stacks) or 1 (level queues)"); t->integrator = v; }
     else if (k == "blocks_per_cu") { if (v < 1 || v > 32) return fail(t, MIPT_E_INVALID, "blocks_per_cu out of range"); t->blocksPerCU = v; }
@@ -246,7 +278,9 @@ int mipt_get_counters(mipt_tracer* t, mipt_counters* out) {
     int rc = mipt_synchronize(t); if (rc) return rc;
     unsigned long long rays = 0;
     HIPCHK(t, hipMemcpy(&rays, t->stats, sizeof rays, hipMemcpyDeviceToHost));
-    out->rays = rays; out->frames = t->frames; out->kernel_ms = t->kernelMs; out->launches = t->launches;
+    unsigned long long shadow = 0;
+    HIPCHK(t, hipMemcpy(&shadow, t->stats + 38, sizeof shadow, hipMemcpyDeviceToHost));
+    out->rays = rays; out->frames = t->frames; out->kernel_ms = t->kernelMs; out->launches = t->launches; out->shadow_rays = shadow;
     return MIPT_OK;
 }
 
@@ -341,6 +375,7 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
         M[4] = mm.metallic; M[5] = mm.opacity; M[6] = mm.n; M[7] = mm.emissiveStrength;
         M[8] = mm.emissiveColor[0]; M[9] = mm.emissiveColor[1]; M[10] = mm.emissiveColor[2]; M[11] = 0.f;
     }
+    if (d->envMap && d->envW && d->envH) build_env_cdf(d->envMap, d->envW, d->envH, s->hEnvCdf);
     auto upload = [&](void** dst, const void* src, size_t bytes) -> bool {
         if (bytes == 0) bytes = 16;
         if (hipMalloc(dst, bytes) != hipSuccess) return false;
@@ -353,12 +388,15 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
         bool ok = upload(&s->dNodes, s->hNodes.data(), s->hNodes.size() * 4) && upload(&s->dRefs, s->hRefs.data(), s->hRefs.size() * 4) &&
                   upload(&s->dShade, shade.data(), shade.size() * 4) && upload(&s->dMats, mats.data(), mats.size() * 4);
         if (ok && d->envMap && d->envW && d->envH) ok = upload(&s->dEnv, d->envMap, (size_t)d->envW * d->envH * 3 * 4);
+        if (ok && s->dEnv) ok = upload(&s->dEnvCdf, s->hEnvCdf.data(), s->hEnvCdf.size() * 4);
         if (!ok) { mipt_scene_destroy(s); return fail(t, MIPT_E_NOMEM, "scene upload failed"); }
     }
     if (bo.refTri.empty()) s->hRefs.clear();
     s->dev.nodes = (const float4*)s->dNodes; s->dev.refs = (const float4*)s->dRefs; s->dev.shade = (const float4*)s->dShade;
     s->dev.mats = (const float4*)s->dMats; s->dev.env = (const float*)s->dEnv;
     s->dev.envW = s->dEnv ? d->envW : 0; s->dev.envH = s->dEnv ? d->envH : 0;
+    s->dev.envCdf = (const float*)s->dEnvCdf;
+    s->dev.neeScale = s->dEnv ? (float)(M_PI / 0.98 / ((double)d->envW * (double)d->envH)) : 0.f;
     memcpy(s->dev.skyColor, d->sky.color, 12); memcpy(s->dev.skyDir, d->sky.dir, 12); s->dev.skyIntensity = d->sky.intensity;
     s->dev.nNodes = (uint32_t)(s->hNodes.size() / 16); s->dev.nRefs = (uint32_t)bo.refTri.size();
     s->dev.wide = bo.width == 4 ? 1u : 0u;
@@ -375,6 +413,7 @@ void mipt_scene_destroy(mipt_scene* s) {
     if (s->dShade) hipFree(s->dShade);
     if (s->dMats) hipFree(s->dMats);
     if (s->dEnv) hipFree(s->dEnv);
+    if (s->dEnvCdf) hipFree(s->dEnvCdf);
     delete s;
 }
 
@@ -388,6 +427,11 @@ int mipt_scene_get_bvh(const mipt_scene* s, float* nodes, uint32_t* n_nodes, flo
 }
 uint32_t mipt_scene_triangle_count(const mipt_scene* s) { return s ? s->nTris : 0; }
 uint32_t mipt_scene_bvh_width(const mipt_scene* s) { return s ? s->bvhWidth : 0; }
+uint64_t mipt_scene_get_env_cdf(const mipt_scene* s, float* out, uint64_t cap) {
+    if (!s) return 0;
+    if (out && cap >= s->hEnvCdf.size()) memcpy(out, s->hEnvCdf.data(), s->hEnvCdf.size() * sizeof(float));
+    return s->hEnvCdf.size();
+}
 int mipt_scene_bvh_was_cached(const mipt_scene* s) { return s && s->bvhFromCache ? 1 : 0; }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -405,6 +449,11 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
     if (t->rngMode == MIPT_RNG_DFS && D > 16) return fail(t, MIPT_E_LIMIT, "rng_mode dfs supports maxDepth <= 16");
     if (frame_stride == 0) frame_stride = 1;
     const uint32_t npix = W * H;
+    // env-map importance sampling: wave-stack integrator with node-keyed streams only, and only with an env map to sample
+    const bool nee = t->estimator == 1;
+    if (nee && (t->rngMode != MIPT_RNG_NODE || t->integrator != 0)) return fail(t, MIPT_E_INVALID, "estimator 1 needs integrator 0 and rng_mode node");
+    if (nee && !sc->dev.envCdf) return fail(t, MIPT_E_INVALID, "estimator 1 needs a scene with an environment map");
+    if (nee && npix >= (1u << 30)) return fail(t, MIPT_E_LIMIT, "viewport too large for estimator 1");
 
     if (t->samplePixels < npix) {
         if (t->sample) hipFree(t->sample);
@@ -425,7 +474,7 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
         // depth-first integrator: no queues
     } else if (t->integrator == 0) {
         // persistent wave stacks: 256 entries per recursion level per wave (see k_wavestack), independent of the viewport
-        wcap = 256u * std::max<uint32_t>(D, 1u) + 256u;
+        wcap = (nee ? 384u : 256u) * std::max<uint32_t>(D, 1u) + 256u;      // estimator 1: up to three rays per hit
         const size_t need = (size_t)persistentBlocks * 4 * wcap;
         if (t->wstackEntries < need) {
             free_queue(t->wstack); t->wstackEntries = 0;
@@ -472,7 +521,7 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
             HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), t->stream));
             StackArgs SA;
             SA.S = sc->dev; SA.F = A.F; SA.stack = t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes; // auto: 8 for an LDS-resident scene, 24 otherwise (measured optima, profiles/r1/exp_min_descend.log)
-            SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (!sc->dev.wide && sc->dev.nNodes * 4 + sc->dev.nRefs * 3 <= 256 ? 8 : 24)); SA.pixCounter = t->counts;
+            SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (!sc->dev.wide && sc->dev.nNodes * 4 + sc->dev.nRefs * 3 <= 256 ? 8 : 24)); SA.pixCounter = t->counts; SA.nee = nee ? 1u : 0u;
             SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npix;
             mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
             if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, t->stream)); }

@@ -21,6 +21,8 @@ struct SceneDev {
     float skyColor[3]; float skyDir[3]; float skyIntensity;
     uint32_t nNodes, nRefs;
     uint32_t wide;            // 0: BVH2 nodes, 1: quantised 4-wide nodes
+    const float* envCdf;      // estimator 1: rowCdf[envH+1], then envH rows of colCdf[envW+1]; nullptr without an env map
+    float neeScale;           // pi / (0.98 * envW * envH)
 };
 
 // Per-frame constants computed once on the host (CUDATracerProg.cu:369-397 computes them per thread).
@@ -53,6 +55,7 @@ struct StackArgs {
     Queue stack;                 // waves * cap entries, wave w owns [w*cap, (w+1)*cap)
     uint32_t refill;             // refill idle lanes once this many are idle (1..64)
     uint32_t minDescend;         // a traversal round stops descending when fewer lanes than this are still at inner nodes
+    uint32_t nee;                // 1: env-map importance sampling estimator (occlusion rays), 0: the reference's estimator
     uint32_t cap;                // entries per wave
     uint32_t* pixCounter;        // next unclaimed pixel of the frame (reset to 0 before the launch)
     float* sample; uint32_t* pixelRays; unsigned long long* stats;

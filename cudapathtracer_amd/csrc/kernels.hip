@@ -470,6 +470,35 @@ MIPT_DEV void load_ref(const float4* lds, const float4* glb, uint32_t i, float4&
     else { const float4* T = glb + (size_t)i * 3; a = T[0]; b = T[1]; c = T[2]; }
 }
 
+// ---- env-map importance sampling (option "estimator" = 1; specification: include/mipt.h, tables built in api.hip) ----
+constexpr uint32_t kShadowBit = 0x80000000u;   // flags carried in the pixel word of a ray record (pixel index < 2^30)
+constexpr uint32_t kNoEnvBit  = 0x40000000u;   //   occlusion ray of the estimator / diffuse child whose miss adds nothing
+constexpr uint32_t kPixMask   = 0x3FFFFFFFu;
+MIPT_DEV uint32_t cdf_find(const float* __restrict__ cdf, uint32_t n, float u) {     // largest i in [0,n-1] with cdf[i] <= u
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1u) { uint32_t mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid; else hi = mid; }
+    return lo;
+}
+MIPT_DEV bool sample_env(const SceneDev& S, float u1, float u2, v3& dir, v3& L, float& wgt) {
+    const uint32_t W = S.envW, H = S.envH;
+    const float* row = S.envCdf;
+    const uint32_t iv = cdf_find(row, H, u1);
+    const float pr = row[iv + 1] - row[iv];
+    const float* col = row + (H + 1) + (size_t)iv * (W + 1);
+    const uint32_t iu = cdf_find(col, W, u2);
+    const float pc = col[iu + 1] - col[iu];
+    if (!(pr > 0.f) || !(pc > 0.f)) return false;
+    const float du1 = (u1 - row[iv]) / pr, du2 = (u2 - col[iu]) / pc;
+    const float theta = (((float)iv + du1) / (float)H) * 3.14159265358979323846f;
+    const float phi = (((float)iu + du2) / (float)W) * 6.28318530717958647692f;      // azimuth + pi
+    float st, ct, sp, cp; det_sincosf(theta, &st, &ct); det_sincosf(phi, &sp, &cp);
+    dir = mk3(st * -sp, ct, st * -cp);
+    const float* px = S.env + ((size_t)iv * W + iu) * 3;
+    L = mk3(px[0], px[1], px[2]);
+    wgt = st * S.neeScale / (pr * pc);
+    return true;
+}
+
 // Lane-utilisation instrumentation (make prof -> libmipt_prof.so, scripts/lane_profile.py).  Wave-level sums land in
 // stats[8..]: [8] traversal rounds, [9] lanes active at round start, [10] node-loop wave iterations (max over lanes),
 // [11] node visits (sum over lanes), [12] leaf-loop wave iterations, [13] triangle tests, [14] full shade batches,
@@ -482,7 +511,7 @@ MIPT_DEV uint32_t wave_sum_u32(uint32_t v) { for (int s = 32; s > 0; s >>= 1) v 
 #define MIPT_PROF(x)
 #endif
 
-template <bool LDS_SCENE, bool WIDE>
+template <bool LDS_SCENE, bool WIDE, bool NEE>
 __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     constexpr int kSqCap = SqCap<LDS_SCENE>::value;
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
@@ -522,7 +551,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     uint32_t* const lstk = ldsStack + threadIdx.x;
     uint32_t deep[(WIDE ? kWideStackCap : kStackCap) - kLdsStack];
     int tsp = 0;
-    uint32_t traced = 0;
+    uint32_t traced = 0, shadowTraced = 0;
     MIPT_PROF(unsigned long long pf[12] = {};)
 
     while (true) {
@@ -539,12 +568,13 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
             const bool has = lane < n;
             Bounce b;
             uint32_t spix = 0, snode = 0, ss0 = 0;
+            bool wantShadow = false, opaque = false; v3 sdir = mk3(0, 0, 1), scon = mk3(0, 0, 0);
             if (has) {
                 const uint32_t e = nF + lane;
                 v3 P = mk3(sq[0 * kSqCap + e], sq[1 * kSqCap + e], sq[2 * kSqCap + e]);
                 v3 sd = mk3(sq[3 * kSqCap + e], sq[4 * kSqCap + e], sq[5 * kSqCap + e]);
                 v3 sb = mk3(sq[6 * kSqCap + e], sq[7 * kSqCap + e], sq[8 * kSqCap + e]);
-                spix = sqi[9 * kSqCap + e]; snode = sqi[10 * kSqCap + e]; ss0 = sqi[11 * kSqCap + e];
+                spix = sqi[9 * kSqCap + e] & (NEE ? kPixMask : 0xFFFFFFFFu); snode = sqi[10 * kSqCap + e]; ss0 = sqi[11 * kSqCap + e];
                 const float su = sq[12 * kSqCap + e], sv = sq[13 * kSqCap + e];
                 const uint32_t tf = sqi[14 * kSqCap + e];
                 const bool front = (tf >> 31) != 0;
@@ -559,8 +589,19 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 Lcg rng; rng.state = node_seed(ss0, snode);
                 b = shade_hit(mat, sf, sd, front, rng);
                 b.f1 = sb * b.f1; b.f2 = sb * b.f2;
+                if constexpr (NEE) {
+                    // the environment seen through the diffuse cap is sampled explicitly: two more draws of this hit's
+                    // stream, one occlusion ray; the diffuse child is flagged so that its own miss adds nothing
+                    opaque = mat.opacity == 1.f;
+                    if (opaque) {
+                        const float u1 = rng.NextFloat(), u2 = rng.NextFloat();
+                        v3 L; float wgt;
+                        if (sample_env(A.S, u1, u2, sdir, L, wgt) && dot3(sdir, sf.N) > 0.02f) { wantShadow = true; scon = b.f2 * (L * wgt); }
+                    }
+                }
             }
-            const uint32_t total = 2u * n;
+            const unsigned long long sm = NEE ? __ballot(wantShadow) : 0ull;
+            const uint32_t total = 2u * n + (uint32_t)__popcll(sm);
             if (sp + total > A.cap) {
                 if (lane == 0) atomicOr(A.stats + 39, 1ull);       // overflow: reported by the host, never written past
             } else {
@@ -571,7 +612,13 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     qc[w] = make_float4(b.f1.z, __uint_as_float(spix), __uint_as_float(snode * 2u), __uint_as_float(ss0));
                     qa[w + 1] = make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x);
                     qb[w + 1] = make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y);
-                    qc[w + 1] = make_float4(b.f2.z, __uint_as_float(spix), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0));
+                    qc[w + 1] = make_float4(b.f2.z, __uint_as_float(spix | (NEE && opaque ? kNoEnvBit : 0u)), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0));
+                }
+                if (NEE && wantShadow) {
+                    const uint32_t w = sp + 2u * n + (uint32_t)__popcll(sm & below);
+                    qa[w] = make_float4(b.o2.x, b.o2.y, b.o2.z, sdir.x);
+                    qb[w] = make_float4(sdir.y, sdir.z, scon.x, scon.y);
+                    qc[w] = make_float4(scon.z, __uint_as_float(spix | kShadowBit), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0));
                 }
                 sp += total;
             }
@@ -585,11 +632,13 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 const uint32_t e = (uint32_t)kSqCap - nT + lane;
                 v3 sd = mk3(sq[3 * kSqCap + e], sq[4 * kSqCap + e], sq[5 * kSqCap + e]);
                 v3 sb = mk3(sq[6 * kSqCap + e], sq[7 * kSqCap + e], sq[8 * kSqCap + e]);
-                const uint32_t spix = sqi[9 * kSqCap + e];
+                const uint32_t fpix = sqi[9 * kSqCap + e], spix = fpix & (NEE ? kPixMask : 0xFFFFFFFFu);
+                const bool shadow = NEE && (fpix & kShadowBit), noEnv = NEE && (fpix & kNoEnvBit);
                 const uint32_t tf = sqi[14 * kSqCap + e];
                 if (tf == 0xFFFFFFFFu) {
-                    add_sample(A.sample, spix, sb * on_miss(A.S, sd));
-                } else {
+                    if (shadow) add_sample(A.sample, spix, sb);                  // unoccluded: the pre-weighted environment term
+                    else if (!noEnv) add_sample(A.sample, spix, sb * on_miss(A.S, sd));
+                } else if (!shadow) {
                     const uint32_t mesh = __float_as_uint(A.S.shade[(size_t)(tf & 0x7FFFFFFFu) * 3].w);
                     Material mat = load_material(A.S, mesh);
                     add_sample(A.sample, spix, sb * (mat.emissive * mat.emissiveStrength));
@@ -630,7 +679,8 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     cur = 0;
                     active = true;
                     traced++;
-                    if (A.pixelRays) atomicAdd(A.pixelRays + pix, 1u);
+                    if constexpr (NEE) if (pix & kShadowBit) shadowTraced++;
+                    if (A.pixelRays) atomicAdd(A.pixelRays + (pix & (NEE ? kPixMask : 0xFFFFFFFFu)), 1u);
                 }
             }
         }
@@ -700,6 +750,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     if (mt_test(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) { h.t = tt; h.u = uu; h.v = vv; h.front = ff; h.ref = (int)i; h.tri = id; }
                 }
                 MIPT_STACK_POP(lstk, deep, tsp, cur);
+                if constexpr (NEE) if ((pix & kShadowBit) && h.tri >= 0) cur = kTerm;      // occlusion ray: any hit ends it
             }
         }
         MIPT_PROF(pf[0]++; pf[1] += (uint32_t)__popcll(__ballot(active)); pf[2] += wave_max_u32(myNodes); pf[3] += wave_sum_u32(myNodes);
@@ -710,7 +761,8 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
             // no room: stay terminated-but-unparked until the queue has been drained
             fin = fin && nF + nT + (uint32_t)__popcll(fm & below) < (uint32_t)kSqCap;
             const uint32_t level = 31u - (uint32_t)__clz((int)node);             // root = 1 -> level 0
-            const bool term = h.tri < 0 || level + 1 >= A.F.maxDepth;             // children would have ttl 0 (CUDATracerProg.cu:433)
+            const bool term = h.tri < 0 || level + 1 >= A.F.maxDepth              // children would have ttl 0 (CUDATracerProg.cu:433)
+                              || (NEE && (pix & kShadowBit));
             const unsigned long long mF = __ballot(fin && !term), mT = __ballot(fin && term);
             if (fin) {
                 const uint32_t e = term ? (uint32_t)kSqCap - 1u - (nT + (uint32_t)__popcll(mT & below)) : nF + (uint32_t)__popcll(mF & below);
@@ -729,14 +781,22 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     // one counter update per wave
     for (int sh = 32; sh > 0; sh >>= 1) traced += __shfl_down(traced, sh);
     if (lane == 0 && traced) atomicAdd(A.stats, (unsigned long long)traced);
+    if constexpr (NEE) {
+        for (int sh = 32; sh > 0; sh >>= 1) shadowTraced += __shfl_down(shadowTraced, sh);
+        if (lane == 0 && shadowTraced) atomicAdd(A.stats + 38, (unsigned long long)shadowTraced);
+    }
     MIPT_PROF(if (lane == 0) for (int k = 0; k < 12; k++) atomicAdd(A.stats + 8 + k, pf[k]);)
 }
 
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
-    const bool lds = !a.S.wide && a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec;
-    if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
-    else if (lds) hipLaunchKernelGGL((k_wavestack<true, false>), dim3(blocks), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((k_wavestack<false, false>), dim3(blocks), dim3(kBlock), 0, s, a);
+    const bool lds = !a.S.wide && !a.nee && a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec;
+    if (a.nee) {
+        if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_wavestack<false, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+    }
+    else if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false>), dim3(blocks), dim3(kBlock), 0, s, a);
+    else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, false>), dim3(blocks), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((k_wavestack<false, false, false>), dim3(blocks), dim3(kBlock), 0, s, a);
 }
 
 // =================================================================================================================

@@ -76,6 +76,7 @@ typedef struct {
     uint64_t frames;        /* frames (samples per pixel) rendered */
     double   kernel_ms;     /* HIP-event time of the integrator kernels */
     uint64_t launches;      /* integrator kernel launches */
+    uint64_t shadow_rays;   /* of `rays`: occlusion rays of estimator 1 (0 for the reference's estimator, which has none) */
 } mipt_counters;
 
 /* per recursion level (0 = primary rays): rays traced, HIP-event time of that level's kernel launches, launches.
@@ -110,7 +111,20 @@ uint32_t mipt_scene_bvh_width(const mipt_scene*);           /* 2 or 4: node layo
                                                              * [origin xyz][ex|ey<<8|ez<<16][qlo.x qlo.y qlo.z qhi.x qhi.y qhi.z: 4 bytes each,
                                                              * one per child][0][0][ref0..ref3]; plane = origin + q * 2^(e-127); unused child
                                                              * = 0x80000000) */
-int  mipt_scene_bvh_was_cached(const mipt_scene*);          /* 1 if the BVH came from desc.bvhCachePath, 0 if it was built */
+int  mipt_scene_bvh_was_cached(const mipt_scene*);
+/* Option "estimator" (mipt_set_option; not in the reference, which has no light sampling):
+ *   0 = the reference's estimator: every radiance term arrives through a traced child ray (CUDATracerProg.cu:426-541);
+ *   1 = env-map importance sampling at opaque hits above the last level: the diffuse child (:518-522) is flagged so that
+ *       its own miss adds nothing; instead one direction is drawn from the environment map's distribution
+ *       p_env ~ (r+g+b) * sin(theta) per texel (two more draws of the hit's stream, after the cone draws; texel by CDF
+ *       inversion, uniform inside the texel) and, if it lies inside the diffuse cap (dot(dir, N) > 0.02) and one
+ *       occlusion ray from the child's origin finds nothing, adds  beta * albedo * rt * L_texel * p_cap / p_env  with
+ *       p_cap = 1 / (2 pi 0.98).  Same expectation as estimator 0, far less variance under a small bright sun.
+ *       Occlusion rays are counted in mipt_counters.shadow_rays (and in .rays).  Needs an env map, integrator 0 and
+ *       rng_mode node.
+ * Sampling tables of estimator 1 (rowCdf[envH+1], then envH rows of colCdf[envW+1]); returns the float count,
+ * 0 without an env map.  No counterpart in the reference (it has no light sampling). */
+uint64_t mipt_scene_get_env_cdf(const mipt_scene*, float* out, uint64_t cap);          /* 1 if the BVH came from desc.bvhCachePath, 0 if it was built */
 
 /* ---- the hot path: PathTracer::Trace (CUDATracer.hpp:352-358; CUDATracerProg.cu:937-963) -------------------
  * One sample per pixel for sample index settings->frameID, folded into acc_dev (w*h*4 floats, running mean with

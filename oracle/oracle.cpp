@@ -412,12 +412,15 @@ struct orc_scene {
     // product's flat BVH
     std::vector<float> fnodes, ftris;
     uint32_t fwidth = 2;             // 2: BVH2 nodes, 4: quantised 4-wide nodes
+    int estimator = 0;
+    std::vector<float> envCdf;       // rowCdf[H+1], then H x colCdf[W+1]
+    float neeScale = 0.f;            // pi / (0.98 * W * H): p_cap * texel solid angle / sin(theta)
 };
 
 namespace {
 
 struct Hit { float t, u, v; int tri; bool front; };   // tri = global id
-struct alignas(128) Counters { uint64_t rays = 0, nodes = 0, tris = 0, hits = 0; };   // one cache line per thread
+struct alignas(128) Counters { uint64_t rays = 0, nodes = 0, tris = 0, hits = 0, shadow = 0; };   // one cache line per thread
 
 // Moller-Trumbore on (v0, e1, e2) -- CUDATracerProg.cu:232-263.  Accepts iff t>0 && t<tmin (strict), or -- when
 // `id`/`bestId` are given (>= 0) -- on an exact tie t==tmin if the candidate's global triangle id is lower.  The
@@ -654,6 +657,65 @@ v3 GGXRandDirInsideCone(Lcg& rng, v3 dir, float size, const MathFns& M) {   // :
 struct Ctx {
     const orc_scene* s; int isect; int rng_mode; const MathFns* M; Counters* c; uint32_t s0; uint32_t pixel_rays;
 };
+
+// ---- env-map importance sampling (estimator 1; specification shared with the product, csrc/api.hip + kernels.hip) ----
+// Tables, in double, in this order: weight(iv,iu) = ((double)r + g + b) * sin(pi (iv + 0.5) / H); per row the running sum
+// divided by the row total (uniform if the row is black); the marginal likewise over row totals; stored as float.
+void build_env_cdf(orc_scene& s) {
+    const uint32_t W = s.envW, H = s.envH;
+    s.envCdf.clear(); s.neeScale = 0.f;
+    if (s.env.empty() || !W || !H) return;
+    s.envCdf.assign((size_t)(H + 1) + (size_t)H * (W + 1), 0.f);
+    float* row = s.envCdf.data(); float* col = row + (H + 1);
+    std::vector<double> rowTotal(H), acc(W + 1);
+    for (uint32_t iv = 0; iv < H; iv++) {
+        const double sinT = sin(M_PI * ((double)iv + 0.5) / (double)H);
+        acc[0] = 0.0;
+        for (uint32_t iu = 0; iu < W; iu++) {
+            const float* p = &s.env[((size_t)iv * W + iu) * 3];
+            acc[iu + 1] = acc[iu] + ((double)p[0] + (double)p[1] + (double)p[2]) * sinT;
+        }
+        rowTotal[iv] = acc[W];
+        float* c = col + (size_t)iv * (W + 1);
+        for (uint32_t iu = 0; iu <= W; iu++) c[iu] = acc[W] > 0.0 ? (float)(acc[iu] / acc[W]) : (float)((double)iu / (double)W);
+        c[W] = 1.0f;
+    }
+    double total = 0.0; for (uint32_t iv = 0; iv < H; iv++) total += rowTotal[iv];
+    double run = 0.0;
+    for (uint32_t iv = 0; iv <= H; iv++) {
+        row[iv] = total > 0.0 ? (float)(run / total) : (float)((double)iv / (double)H);
+        if (iv < H) run += rowTotal[iv];
+    }
+    row[H] = 1.0f;
+    s.neeScale = (float)(M_PI / 0.98 / ((double)W * (double)H));
+}
+// largest i in [0, n-1] with cdf[i] <= u  (cdf[0] = 0, cdf[n] = 1 > u)
+inline uint32_t cdf_find(const float* cdf, uint32_t n, float u) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid; else hi = mid; }
+    return lo;
+}
+// one direction from the table; returns false when the texel has no probability mass.  L = its radiance,
+// wgt = p_cap / p_env for a direction inside the diffuse cap.
+inline bool sample_env(const orc_scene& s, const MathFns& M, float u1, float u2, v3* dir, v3* L, float* wgt) {
+    const uint32_t W = s.envW, H = s.envH;
+    const float* row = s.envCdf.data(); 
+    const uint32_t iv = cdf_find(row, H, u1);
+    const float pr = row[iv + 1] - row[iv];
+    const float* col = row + (H + 1) + (size_t)iv * (W + 1);
+    const uint32_t iu = cdf_find(col, W, u2);
+    const float pc = col[iu + 1] - col[iu];
+    if (!(pr > 0.f) || !(pc > 0.f)) return false;
+    const float du1 = (u1 - row[iv]) / pr, du2 = (u2 - col[iu]) / pc;
+    const float theta = (((float)iv + du1) / (float)H) * 3.14159265358979323846f;
+    const float phi = (((float)iu + du2) / (float)W) * 6.28318530717958647692f;     // azimuth + pi
+    float st, ct, sp, cp; M.sincos(theta, &st, &ct); M.sincos(phi, &sp, &cp);
+    *dir = mk(st * -sp, ct, st * -cp);
+    const float* p = &s.env[((size_t)iv * W + iu) * 3];
+    *L = mk(p[0], p[1], p[2]);
+    *wgt = st * s.neeScale / (pr * pc);
+    return true;
+}
 v3 OnMiss(const Ctx& k, v3 d) {                                // :796-846
     const orc_scene& s = *k.s;
     if (s.env.empty()) {
@@ -675,12 +737,12 @@ v3 OnMiss(const Ctx& k, v3 d) {                                // :796-846
     v3 p1 = (dv) * p00 + (1 - dv) * p00;
     return du * p1 + (1 - du) * p0;
 }
-v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node) {   // :426-541
+v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noEnv = false) {   // :426-541
     v3 color = mk(0, 0, 0);
     if (ttl <= 0) return color;
     k.pixel_rays++;
     Hit h = isect(*k.s, k.isect, o, d, k.c);
-    if (h.tri < 0) return OnMiss(k, d);
+    if (h.tri < 0) return noEnv ? color : OnMiss(k, d);
     const OMesh& m = k.s->meshes[k.s->triMesh[h.tri]];
     uint32_t lt = k.s->triLocal[h.tri];
     const orc_material& mat = m.mat;
@@ -725,7 +787,18 @@ v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node) {   // :
         d2 = RandDirInsideCone(*rng, N, 0.49f, *k.M);
         o2 = P + N * 1e-6f;
     }
-    c = LaunchRayRecur(k, o2, d2, ttl - 1, dfs, node * 2 + 1);    // :525
+    // estimator 1: the environment seen by the diffuse child is sampled explicitly (one occlusion ray) instead
+    const bool nee = k.s->estimator == 1 && k.rng_mode == ORC_RNG_NODE && !k.s->envCdf.empty() && mat.opacity == 1.f && ttl - 1 > 0;
+    c = LaunchRayRecur(k, o2, d2, ttl - 1, dfs, node * 2 + 1, nee);    // :525
+    if (nee) {
+        float u1 = rng->NextFloat(), u2 = rng->NextFloat();
+        v3 wdir, L; float wgt;
+        if (sample_env(*k.s, *k.M, u1, u2, &wdir, &L, &wgt) && dot3(wdir, N) > 0.02f) {
+            k.pixel_rays++; k.c->shadow++;
+            Hit sh = isect(*k.s, k.isect, o2, wdir, k.c);
+            if (sh.tri < 0) c = c + L * wgt;
+        }
+    }
     color = color + col * c * rt * ((mat.opacity == 1.f) ? 1.f : (1 - mat.opacity));   // :526
     color = color + ld3(mat.emissiveColor) * mat.emissiveStrength;                     // :528
     return color;
@@ -827,6 +900,7 @@ orc_scene* orc_scene_create(const orc_scene_desc* d) {
     orc_scene* s = new orc_scene();
     s->sky = d->sky;
     if (d->envMap && d->envW && d->envH) { s->envW = d->envW; s->envH = d->envH; s->env.assign(d->envMap, d->envMap + (size_t)d->envW * d->envH * 3); }
+    build_env_cdf(*s);
     uint32_t base = 0;
     for (uint32_t i = 0; i < d->meshCnt; i++) {
         const orc_mesh_desc& md = d->meshes[i];
@@ -848,6 +922,11 @@ int orc_scene_set_flat_bvh(orc_scene* s, const float* nodes, uint32_t n_nodes, c
     s->ftris.assign(tris, tris + (size_t)n_refs * 12);
     s->fwidth = 2;
     return 0;
+}
+int orc_scene_set_estimator(orc_scene* s, int e) { if (e != 0 && e != 1) return 1; s->estimator = e; return 0; }
+uint64_t orc_scene_get_env_cdf(const orc_scene* s, float* out, uint64_t cap) {
+    if (out && cap >= s->envCdf.size()) memcpy(out, s->envCdf.data(), s->envCdf.size() * sizeof(float));
+    return s->envCdf.size();
 }
 int orc_scene_set_flat_width(orc_scene* s, uint32_t width) {
     if (width != 2 && width != 4) return 1;
@@ -914,7 +993,7 @@ int orc_trace_rays(const orc_scene* s, int mode, const float* origins, const flo
             o.t = h.t; o.u = h.u; o.v = h.v; o.tri = h.tri; o.mesh = h.tri >= 0 ? (int32_t)s->triMesh[h.tri] : -1; o.front = h.front ? 1 : 0;
         }
     });
-    if (stats) { memset(stats, 0, sizeof *stats); for (auto& c : cs) { stats->rays += c.rays; stats->node_visits += c.nodes; stats->tri_tests += c.tris; stats->hits += c.hits; } }
+    if (stats) { memset(stats, 0, sizeof *stats); for (auto& c : cs) { stats->rays += c.rays; stats->node_visits += c.nodes; stats->tri_tests += c.tris; stats->hits += c.hits; stats->shadow_rays += c.shadow; } }
     return 0;
 }
 
@@ -952,7 +1031,7 @@ int orc_render(const orc_scene* s, const orc_settings* st, int isect_mode, int r
             }
         });
     }
-    if (stats) { memset(stats, 0, sizeof *stats); for (auto& c : cs) { stats->rays += c.rays; stats->node_visits += c.nodes; stats->tri_tests += c.tris; stats->hits += c.hits; } }
+    if (stats) { memset(stats, 0, sizeof *stats); for (auto& c : cs) { stats->rays += c.rays; stats->node_visits += c.nodes; stats->tri_tests += c.tris; stats->hits += c.hits; stats->shadow_rays += c.shadow; } }
     return 0;
 }
 

@@ -67,6 +67,7 @@ typedef struct {
     uint64_t node_visits; /* inner-node visits (FLAT only) */
     uint64_t tri_tests;   /* triangle tests */
     uint64_t hits;        /* rays that hit something */
+    uint64_t shadow_rays; /* of `rays`: occlusion rays of the env-map importance sampling estimator (estimator 1) */
 } orc_stats;
 
 typedef struct { float t, u, v; int32_t tri; int32_t mesh; int32_t front; } orc_hit; /* tri = global triangle id, -1 = miss */
@@ -109,6 +110,17 @@ int orc_trace_rays(const orc_scene*, int isect, const float* origins, const floa
  * Renders frames [first_frame, first_frame+n_frames) of the rectangle [x0,x1)x[y0,y1) into acc (running mean,
  * w*h*4 floats, row 0 = bottom) and ldr (w*h*4 bytes, may be NULL).  sample (w*h*3 floats, may be NULL) receives the
  * radiance of the LAST frame rendered; rays_per_pixel (w*h uint32, may be NULL) its per-pixel ray count. */
+/* Estimator (not in the reference, which has no light sampling -- SURVEY 8f rank 4; the product's option "estimator"):
+ *   0 = the reference's: every radiance term arrives through a traced child ray;
+ *   1 = env-map importance sampling at opaque hits: the diffuse child no longer collects the environment when it
+ *       misses; instead one direction is drawn from the environment map's luminance x sin(theta) distribution
+ *       (two extra draws of the hit's stream, after the cone draws) and, if it lies inside the diffuse cap
+ *       (cos > 0.02) and is unoccluded, adds  albedo * rt * L * p_cap / p_env.  Same expectation as estimator 0.
+ * Requires an env map and RNG_NODE; ignored otherwise. */
+int orc_scene_set_estimator(orc_scene*, int estimator);
+/* the sampling tables of estimator 1: rowCdf[H+1] then H rows of colCdf[W+1]; returns the float count (0 = no env map) */
+uint64_t orc_scene_get_env_cdf(const orc_scene*, float* out, uint64_t cap);
+
 int orc_render(const orc_scene*, const orc_settings* s, int isect, int rng_mode, int math_mode,
                uint32_t first_frame, uint32_t n_frames, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
                float* acc, uint8_t* ldr, float* sample, uint32_t* rays_per_pixel, orc_stats* stats, int nthreads);

@@ -48,7 +48,8 @@ class SceneDesc(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("hits", C.c_uint64)]
+    _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("hits", C.c_uint64),
+                ("shadow_rays", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("tri", "<i4"), ("mesh", "<i4"), ("front", "<i4")])
@@ -82,6 +83,9 @@ lib.orc_scene_triangle_count.restype = C.c_uint32
 lib.orc_scene_set_flat_bvh.argtypes = [_vp, _vp, C.c_uint32, _vp, C.c_uint32]
 lib.orc_check_flat_bvh.argtypes = [_vp, C.c_char_p, C.c_uint32]
 lib.orc_scene_set_flat_width.argtypes = [_vp, C.c_uint32]
+lib.orc_scene_set_estimator.argtypes = [_vp, C.c_int]
+lib.orc_scene_get_env_cdf.argtypes = [_vp, _vp, C.c_uint64]
+lib.orc_scene_get_env_cdf.restype = C.c_uint64
 lib.orc_trace_rays.argtypes = [_vp, C.c_int, _vp, _vp, C.c_uint32, _vp, C.POINTER(Stats), C.c_int]
 lib.orc_render.argtypes = [_vp, C.POINTER(Settings), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(Stats), C.c_int]
@@ -168,6 +172,17 @@ class Scene:
         lib.orc_scene_set_flat_bvh(self.h, _ptr(nodes), len(nodes), _ptr(refs), len(refs))
         if lib.orc_scene_set_flat_width(self.h, width) != 0:
             raise ValueError("width must be 2 or 4")
+
+    def set_estimator(self, estimator):
+        """0 = the reference's estimator, 1 = env-map importance sampling at opaque hits (oracle.h)."""
+        if lib.orc_scene_set_estimator(self.h, estimator) != 0:
+            raise ValueError("estimator must be 0 or 1")
+
+    def env_cdf(self):
+        n = lib.orc_scene_get_env_cdf(self.h, None, 0)
+        out = np.zeros(n, np.float32)
+        lib.orc_scene_get_env_cdf(self.h, _ptr(out), n)
+        return out
 
     def check_flat_bvh(self):
         buf = C.create_string_buffer(256)

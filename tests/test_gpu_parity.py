@@ -336,3 +336,60 @@ def test_dfs_order_integrator_is_bit_identical_to_the_oracle(tracer, ptlib, orac
         tracer.set_option("rng_mode", ptlib.RNG_NODE)
         tracer.set_option("count_pixel_rays", 0)
         tracer.free(acc), tracer.free(ldr)
+
+
+@pytest.mark.parametrize("width", [2, 4], ids=["bvh2", "q4"])
+def test_env_importance_sampling_estimator_matches_oracle(tracer, ptlib, oracle, width):
+    """option estimator = 1 (include/mipt.h): identical ray trees incl. the occlusion rays, radiance to the usual
+    tolerance, and the shadow-ray counter equals the oracle's."""
+    rng = np.random.default_rng(3)
+    env = (rng.uniform(0.2, 1.0, (32, 64, 3)) ** 2).astype(np.float32)
+    env[6:9, 10:14] = 40.0
+    env[20:, :5] = 0.0
+    data = ptlib.builtin_scene(1, env)
+    sc = ptlib.Scene(tracer, data, node_width=width)
+    o = oracle.Scene(data)
+    o.set_flat_bvh(*sc.flat())
+    o.set_estimator(1)
+    assert np.array_equal(sc.env_cdf().view(np.uint32), o.env_cdf().view(np.uint32))
+    w, h, depth = 112, 80, 6
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.DEFAULT_CAMERA), w, h, depth)
+    acc, ldr = dev_buffers(tracer, w, h)
+    tracer.set_option("estimator", 1)
+    tracer.set_option("count_pixel_rays", 1)
+    try:
+        exp_acc = np.zeros((h, w, 4), np.float32)
+        for frame in (0, 1, 7):
+            s.frameID = frame
+            tracer.reset_counters()
+            tracer.trace(sc, s, acc, ldr)
+            rgb, rays = tracer.last_sample(w * h, rays=True)
+            r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, frame, 1, acc=exp_acc, nthreads=16)
+            assert np.array_equal(rays.reshape(h, w), r["rays"]), frame
+            c = tracer.counters()
+            assert c.rays == r["stats"].rays and c.shadow_rays == r["stats"].shadow_rays and c.shadow_rays > 0.05 * c.rays
+            assert rel_err(rgb.reshape(h, w, 3), r["sample"]).max() < RTOL, frame
+            assert rel_err(tracer.download(acc, (h, w, 4), np.float32), r["acc"]).max() < RTOL
+            l = tracer.download(ldr, (h, w, 4), np.uint8)
+            assert np.abs(l.astype(int) - r["ldr"].astype(int)).max() <= 1
+        # the reference's estimator is untouched by the option's existence
+        tracer.set_option("estimator", 0)
+        tracer.reset_counters()
+        s.frameID = 0
+        tracer.trace(sc, s, acc, ldr)
+        assert tracer.counters().shadow_rays == 0
+        # needs an env map, node-keyed streams and the wave-stack integrator
+        tracer.set_option("estimator", 1)
+        with pytest.raises(ptlib.MiptError):
+            tracer.trace(ptlib.Scene(tracer, ptlib.builtin_scene(0)), s, acc, ldr)
+        tracer.set_option("integrator", 1)
+        with pytest.raises(ptlib.MiptError):
+            tracer.trace(sc, s, acc, ldr)
+        tracer.set_option("integrator", 0)
+        with pytest.raises(ptlib.MiptError):
+            tracer.set_option("estimator", 2)
+    finally:
+        tracer.set_option("estimator", 0)
+        tracer.set_option("integrator", 0)
+        tracer.set_option("count_pixel_rays", 0)
+        tracer.free(acc), tracer.free(ldr)
