@@ -69,6 +69,8 @@ public:
 
 class HIPTracerProg : public PathTracer {     // stands where CUDATracerProg stood (CUDATracerProg.hpp, CUDATracerProg.cu:925-963)
 public:
+    // tuning / estimator options of libmipt; not part of the reference's interface
+    void SetOption(const char* key, long long value) { detail::Check(mipt_set_option(detail::DefaultTracer(), key, value), "mipt_set_option"); }
     void Trace(CUDAScene& scn, TypedBuffer<PathTraceSettings>& settings, float* accBuffer, char* buffer) override {
         const PathTraceSettings& st = settings.Get<0>();
         detail::Check(mipt_trace(detail::DefaultTracer(), scn.handle(), reinterpret_cast<const mipt_settings*>(&st), accBuffer,

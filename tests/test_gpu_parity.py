@@ -393,3 +393,25 @@ def test_env_importance_sampling_estimator_matches_oracle(tracer, ptlib, oracle,
         tracer.set_option("integrator", 0)
         tracer.set_option("count_pixel_rays", 0)
         tracer.free(acc), tracer.free(ldr)
+
+
+def test_large_scene_parallel_build_q4_and_cache_on_gpu(tracer, ptlib, oracle, tmp_path):
+    # 131 k triangles: BVH built by spliced child builders, collapsed to 4-wide nodes, written to and reloaded from the
+    # cache file; both scenes must trace bit-identically to the oracle walking the same nodes
+    v, i = ptlib.grid_mesh(256, 8.0, 1.0, 1)
+    data = ptlib.SceneData([(v, i, ptlib.make_material())], ptlib.SkyLight())
+    cache = str(tmp_path / "grid.bvh")
+    built = ptlib.Scene(tracer, data, bvh_cache=cache)
+    loaded = ptlib.Scene(tracer, data, bvh_cache=cache)
+    assert built.bvh_width == 4 and not built.bvh_was_cached and loaded.bvh_was_cached
+    o = oracle.Scene(data)
+    o.set_flat_bvh(*loaded.flat())
+    assert o.check_flat_bvh() == (0, "")
+    og, dg = random_rays(200000, 5, -7, 7)
+    og[:, 1] = 1.5 + np.abs(og[:, 1]) * 0.2
+    dg[:, 1] = -np.abs(dg[:, 1]) - 0.05
+    dg /= np.linalg.norm(dg, axis=1, keepdims=True)
+    c, _ = o.trace_rays(oracle.ISECT_FLAT, og, dg, nthreads=16)
+    assert (c["tri"] >= 0).mean() > 0.5
+    for sc in (built, loaded):
+        assert hits_equal(tracer.trace_rays(sc, og, dg), c) == 0
