@@ -343,7 +343,9 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
     if (bp.builder != MIPT_BVH_SBVH && bp.builder != MIPT_BVH_MEDIAN) return fail(t, MIPT_E_INVALID, "unknown bvhBuilder");
     if (d->maxLeafSize) bp.maxLeafSize = d->maxLeafSize;
     if (d->splitAlpha > 0.f) bp.splitAlpha = d->splitAlpha;
-    if (d->sahTriCost > 0.f) bp.triCost = d->sahTriCost;
+    // SAH triangle cost: measured optima are 1.5 for a scene traversed as BVH2 from LDS (a few dozen triangles) and 3.0
+    // for everything that ends up in 4-wide nodes (profiles/r1/exp_sah_tricost_leafsize.log, exp_sah_q4.log)
+    bp.triCost = d->sahTriCost > 0.f ? d->sahTriCost : (tris.size() <= 64 ? 1.5f : 3.0f);
     bp.nodeWidth = d->nodeWidth;
     if (bp.nodeWidth != 0 && bp.nodeWidth != 2 && bp.nodeWidth != 4) return fail(t, MIPT_E_INVALID, "nodeWidth must be 0, 2 or 4");
     BvhOut bo;

@@ -56,29 +56,32 @@ int ceil_log2(uint32_t n) { int l = 0; while ((1u << l) < n && l < 31) l++; retu
 constexpr int kTaskMin = 1 << 15;        // references: subtrees at least this big are built by a child Builder
 constexpr size_t kSortChunk = 1 << 16;   // smallest range worth sorting on another thread
 
-// extra worker threads that may still be started (the calling thread is not counted)
-std::atomic<int> g_spare{0};
-bool take_thread() {
-    int v = g_spare.load(std::memory_order_relaxed);
-    while (v > 0) if (g_spare.compare_exchange_weak(v, v - 1)) return true;
-    return false;
-}
-void give_thread() { g_spare.fetch_add(1); }
+// extra worker threads one build may still start (the calling thread is not counted); one budget per build_bvh call,
+// shared by that build's child builders, so concurrent builds on different host threads do not interfere
+struct ThreadBudget {
+    std::atomic<int> spare{0};
+    bool take() {
+        int v = spare.load(std::memory_order_relaxed);
+        while (v > 0) if (spare.compare_exchange_weak(v, v - 1)) return true;
+        return false;
+    }
+    void give() { spare.fetch_add(1); }
+};
 
 template <class It, class Cmp>
-void psort(It b, It e, Cmp c) {
+void psort(It b, It e, Cmp c, ThreadBudget* tb) {
     const size_t n = (size_t)(e - b);
-    if (n < 2 * kSortChunk || !take_thread()) { std::sort(b, e, c); return; }
+    if (n < 2 * kSortChunk || !tb->take()) { std::sort(b, e, c); return; }
     It m = b + n / 2;
-    auto f = std::async(std::launch::async, [=] { psort(b, m, c); give_thread(); });
-    psort(m, e, c);
+    auto f = std::async(std::launch::async, [=] { psort(b, m, c, tb); tb->give(); });
+    psort(m, e, c, tb);
     f.get();
     std::inplace_merge(b, m, e, c);
 }
 
 class Builder {
 public:
-    Builder(const std::vector<TriPos>& t, const BvhParams& p, BvhOut& o) : T(t), P(p), O(o) {}
+    Builder(const std::vector<TriPos>& t, const BvhParams& p, BvhOut& o, ThreadBudget* tb) : T(t), P(p), O(o), TB(tb) {}
 
     // a subtree of a parent Builder: `refs` are its references, the result (root reference, local indices) is
     // returned and the nodes / references land in this Builder's own output
@@ -127,7 +130,7 @@ public:
     }
 
 private:
-    const std::vector<TriPos>& T; const BvhParams& P; BvhOut& O;
+    const std::vector<TriPos>& T; const BvhParams& P; BvhOut& O; ThreadBudget* TB;
     std::vector<Ref> stk;          // a node's references are the last `n` entries
     std::vector<Box> rightB;
     float minOverlap = 0;
@@ -155,7 +158,7 @@ private:
             float ca = a.b.mn[dim] + a.b.mx[dim], cb = b.b.mn[dim] + b.b.mx[dim];
             if (ca == cb) return a.tri < b.tri;
             return ca < cb;
-        });
+        }, TB);
     }
 
     // ---- median split over the reference stack (Types.hpp:312-413) --------------------------------------------
@@ -220,11 +223,11 @@ private:
             std::vector<Ref> rrefs(stk.end() - R.n, stk.end());
             stk.resize(stk.size() - R.n);
             BvhOut co;
-            Builder child(T, P, co);
+            Builder child(T, P, co, TB);
             uint32_t cr = 0;
             auto job = [&] { cr = child.run_subtree(std::move(rrefs), R, level + 1, minOverlap); };
-            if (take_thread()) {
-                auto f = std::async(std::launch::async, [&] { job(); give_thread(); });
+            if (TB->take()) {
+                auto f = std::async(std::launch::async, [&] { job(); TB->give(); });
                 lr = build(L, level + 1);
                 f.get();
             } else {
@@ -461,9 +464,9 @@ std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOu
     int threads = (int)std::thread::hardware_concurrency();
     if (const char* e = std::getenv("MIPT_BUILD_THREADS")) threads = std::atoi(e);
     threads = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
-    g_spare.store(threads - 1);
+    ThreadBudget budget; budget.spare.store(threads - 1);
     if (p.nodeWidth != 0 && p.nodeWidth != 2 && p.nodeWidth != 4) return "nodeWidth must be 0 (auto), 2 or 4";
-    Builder b(tris, p, out);
+    Builder b(tris, p, out, &budget);
     std::string err = b.run();
     if (!err.empty()) return err;
     out.width = 2; out.stackNeed = out.maxDepth + 2;

@@ -28,7 +28,8 @@ struct BvhParams {
     float    splitAlpha = 1.0e-5f;   // SplitBVHBuilder.hpp:67
     // SAH constants: the reference's `Platform` is undeclared.  NVIDIA's default Platform uses 1 / 1; on
     // gfx950 a Moller-Trumbore test issues ~75 VALU instructions against ~50 for a two-box node visit, and the
-    // measured optimum (profiles/r1/exp_sah_tricost_leafsize.log) is 1 / 1.5.
+    // measured optimum (profiles/r1/exp_sah_tricost_leafsize.log) is 1 / 1.5 for BVH2 traversal; the C-ABI picks 3.0
+    // for scenes that end up in 4-wide nodes (profiles/r1/exp_sah_q4.log).
     float    nodeCost = 1.0f;    // getNodeCost(n) = nodeCost * n
     float    triCost = 1.5f;     // getTriangleCost(n) = triCost * n
     uint32_t minLeafSize = 1;

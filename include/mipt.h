@@ -50,7 +50,7 @@ typedef struct {
     uint32_t bvhBuilder;                                /* MIPT_BVH_* */
     uint32_t maxLeafSize;                               /* 0 = default (4); at most 15 */
     float    splitAlpha;                                /* SBVH spatial-split threshold; 0 = reference default 1e-5 */
-    float    sahTriCost;                                /* SAH cost of one triangle test relative to a node visit; 0 = default (1.5) */
+    float    sahTriCost;                                /* SAH cost of one triangle test relative to a node visit; 0 = default (1.5 up to 64 triangles, else 3.0) */
     uint32_t nodeWidth;                                 /* 2 = fp32 BVH2 nodes; 4 = the BVH2 collapsed to 4 children per node with
                                                            child boxes quantised to 8 bits per plane (still 64 B per node, about
                                                            half the node visits); 0 = auto: 2 if the scene fits the kernels'
