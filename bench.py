@@ -43,7 +43,7 @@ def parse():
     p.add_argument("--integrator", type=int, default=0, help="0 persistent wave stacks (default), 1 level-synchronous queues")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (default); gloo = rehearsal of the N>1 flow through host memory")
     p.add_argument("--node-width", type=int, default=0, help="BVH node layout: 0 library default, 2 fp32 BVH2, 4 quantised 4-wide")
-    p.add_argument("--estimator", type=int, default=0, help="0 the reference's estimator (default, the parity configuration); 1 env-map importance sampling with occlusion rays")
+    p.add_argument("--estimator", type=int, default=0, help="0 the reference's estimator (default, the parity configuration); 1 env-map / emitter sampling with occlusion rays")
     p.add_argument("--traffic-gb", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC run (GB)")
     return p.parse_args()
 
@@ -185,7 +185,8 @@ def main():
     if rank == 0:
         nn, nr = (len(x) for x in sc.bvh())
         if a.integrator == 0:    # one k_wavestack launch per frame traces every ray of the frame
-            kernel_name = "mipt::k_wavestack<%s>" % ("false, true" if sc.bvh_width == 4 else "true, false" if nn * 4 + nr * 3 <= 256 else "false, false")   # <LDS scene, 4-wide>
+            lds = sc.bvh_width == 2 and nn * 4 + nr * 3 <= 256 and not a.estimator          # <LDS scene, 4-wide nodes, light sampling>
+            kernel_name = "mipt::k_wavestack<%s, %s, %s>" % tuple("true" if x else "false" for x in (lds, sc.bvh_width == 4, bool(a.estimator)))
             sec_rays, sec_ms, sec_launches = float(cnt.rays), prof.ms[0], prof.launches[0]
         else:                    # k_level<false,*> launches carry the non-primary levels
             kernel_name = "mipt::k_level<false,*>"
@@ -233,7 +234,7 @@ def main():
                        "triangles": data.triangle_count, "bvh": "sbvh" + ("-q4" if sc.bvh_width == 4 else ""), "rng": "node", "integrator": "wave-stacks" if a.integrator == 0 else "level-queues", "parallelism": f"sample-striding x{world}",
                        "env_map": None if data.env is None else "synthetic 2048x1024"},
             "spp_per_s": round(a.steps * world / dt, 3), "rays_per_step_per_gpu": round(total_rays / a.steps / world, 1),
-            "shadow_rays": round(total_shadow / a.steps / world, 1), "estimator": "reference" if a.estimator == 0 else "env-map importance sampling", "kernel_ms_per_step": round(cnt.kernel_ms / a.steps, 3),
+            "shadow_rays": round(total_shadow / a.steps / world, 1), "estimator": "reference" if a.estimator == 0 else "light sampling (env map + emissive triangles)", "kernel_ms_per_step": round(cnt.kernel_ms / a.steps, 3),
             "level_ms": [round(prof.ms[k] / a.steps, 3) for k in range(depth)] if a.integrator else None,
             "level_mrays": [round(prof.rays[k] / a.steps / 1e6, 2) for k in range(depth)] if a.integrator else None,
             "accumulate_ms": round(prof.accumulate_ms / a.steps, 3),

@@ -91,6 +91,8 @@ lib.mipt_scene_triangle_count.restype = C.c_uint32
 lib.mipt_scene_bvh_was_cached.argtypes = [_vp]
 lib.mipt_scene_get_env_cdf.argtypes = [_vp, _vp, C.c_uint64]
 lib.mipt_scene_get_env_cdf.restype = C.c_uint64
+lib.mipt_scene_get_emitters.argtypes = [_vp, _vp, _vp, C.c_uint64]
+lib.mipt_scene_get_emitters.restype = C.c_uint64
 lib.mipt_scene_bvh_width.argtypes = [_vp]
 lib.mipt_scene_bvh_width.restype = C.c_uint32
 lib.mipt_trace.argtypes = [_vp, _vp, C.POINTER(Settings), _vp, _vp]
@@ -290,6 +292,13 @@ class Scene:
         out = np.zeros(n, np.float32)
         lib.mipt_scene_get_env_cdf(self.h, _ptr(out), n)
         return out
+
+    def emitters(self):
+        n = lib.mipt_scene_get_emitters(self.h, None, None, 0)
+        tris, cdf = np.zeros((n, 15), np.float32), np.zeros(n + 1 if n else 0, np.float32)
+        if n:
+            lib.mipt_scene_get_emitters(self.h, _ptr(tris), _ptr(cdf), n)
+        return tris, cdf
 
     def flat(self):
         """(nodes, refs, width): what the oracle's set_flat_bvh takes."""

@@ -57,6 +57,8 @@ struct mipt_scene {
     SceneDev dev = {};
     void* dNodes = nullptr; void* dRefs = nullptr; void* dShade = nullptr; void* dMats = nullptr; void* dEnv = nullptr; void* dEnvCdf = nullptr;
     std::vector<float> hEnvCdf;
+    void* dEmitTri = nullptr; void* dEmitCdf = nullptr;
+    std::vector<float> hEmitTri, hEmitCdf;      // estimator 1: emissive triangles (15 floats each) and their area CDF
     std::vector<float> hNodes, hRefs;    // host copies for mipt_scene_get_bvh
     uint32_t nTris = 0;
     uint32_t bvhWidth = 2;
@@ -181,6 +183,38 @@ void build_env_cdf(const float* env, uint32_t W, uint32_t H, std::vector<float>&
         if (iv < H) run += rowTotal[iv];
     }
     row[H] = 1.0f;
+}
+
+// Emitter table of estimator 1 (include/mipt.h): every triangle, in global id order, of a mesh with emissiveStrength > 0,
+// a non-black emissive colour and a non-zero area.  In double from the float vertices: c = cross(e1, e2),
+// area = |c| / 2, unit normal = c / |c|; CDF = running area / total area as float; Le = colour * strength in float.
+float build_emitters(const mipt_scene_desc* d, const std::vector<TriPos>& tris, const std::vector<uint32_t>& triMesh,
+                     std::vector<float>& tab, std::vector<float>& cdf) {
+    tab.clear(); cdf.clear();
+    std::vector<double> area;
+    for (size_t g = 0; g < tris.size(); g++) {
+        const mipt_material& mt = d->meshes[triMesh[g]].material;
+        if (!(mt.emissiveStrength > 0.f) || !(mt.emissiveColor[0] > 0.f || mt.emissiveColor[1] > 0.f || mt.emissiveColor[2] > 0.f)) continue;
+        const TriPos& tp = tris[g];
+        float e1[3], e2[3];
+        for (int a = 0; a < 3; a++) { e1[a] = tp.v[1][a] - tp.v[0][a]; e2[a] = tp.v[2][a] - tp.v[0][a]; }
+        const double cx = (double)e1[1] * e2[2] - (double)e2[1] * e1[2], cy = (double)e1[2] * e2[0] - (double)e2[2] * e1[0],
+                     cz = (double)e1[0] * e2[1] - (double)e2[0] * e1[1];
+        const double len = sqrt(cx * cx + cy * cy + cz * cz);
+        if (!(len > 0.0)) continue;
+        const float rec[15] = { tp.v[0][0], tp.v[0][1], tp.v[0][2], e1[0], e1[1], e1[2], e2[0], e2[1], e2[2],
+                                (float)(cx / len), (float)(cy / len), (float)(cz / len),
+                                mt.emissiveColor[0] * mt.emissiveStrength, mt.emissiveColor[1] * mt.emissiveStrength, mt.emissiveColor[2] * mt.emissiveStrength };
+        tab.insert(tab.end(), rec, rec + 15);
+        area.push_back(0.5 * len);
+    }
+    if (area.empty()) return 0.f;
+    double total = 0.0; for (double a : area) total += a;
+    cdf.resize(area.size() + 1);
+    double run = 0.0;
+    for (size_t i = 0; i <= area.size(); i++) { cdf[i] = (float)(run / total); if (i < area.size()) run += area[i]; }
+    cdf[area.size()] = 1.0f;
+    return (float)(total / (2.0 * M_PI * 0.98));
 }
 
 bool save_bvh_cache(const char* path, uint64_t key, uint32_t nTris, const BvhOut& bo) {
@@ -378,6 +412,7 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
         M[8] = mm.emissiveColor[0]; M[9] = mm.emissiveColor[1]; M[10] = mm.emissiveColor[2]; M[11] = 0.f;
     }
     if (d->envMap && d->envW && d->envH) build_env_cdf(d->envMap, d->envW, d->envH, s->hEnvCdf);
+    const float emitScale = build_emitters(d, tris, triMesh, s->hEmitTri, s->hEmitCdf);
     auto upload = [&](void** dst, const void* src, size_t bytes) -> bool {
         if (bytes == 0) bytes = 16;
         if (hipMalloc(dst, bytes) != hipSuccess) return false;
@@ -391,6 +426,7 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
                   upload(&s->dShade, shade.data(), shade.size() * 4) && upload(&s->dMats, mats.data(), mats.size() * 4);
         if (ok && d->envMap && d->envW && d->envH) ok = upload(&s->dEnv, d->envMap, (size_t)d->envW * d->envH * 3 * 4);
         if (ok && s->dEnv) ok = upload(&s->dEnvCdf, s->hEnvCdf.data(), s->hEnvCdf.size() * 4);
+        if (ok && !s->hEmitCdf.empty()) ok = upload(&s->dEmitTri, s->hEmitTri.data(), s->hEmitTri.size() * 4) && upload(&s->dEmitCdf, s->hEmitCdf.data(), s->hEmitCdf.size() * 4);
         if (!ok) { mipt_scene_destroy(s); return fail(t, MIPT_E_NOMEM, "scene upload failed"); }
     }
     if (bo.refTri.empty()) s->hRefs.clear();
@@ -398,6 +434,8 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
     s->dev.mats = (const float4*)s->dMats; s->dev.env = (const float*)s->dEnv;
     s->dev.envW = s->dEnv ? d->envW : 0; s->dev.envH = s->dEnv ? d->envH : 0;
     s->dev.envCdf = (const float*)s->dEnvCdf;
+    s->dev.emitTri = (const float*)s->dEmitTri; s->dev.emitCdf = (const float*)s->dEmitCdf;
+    s->dev.nEmit = s->dEmitCdf ? (uint32_t)(s->hEmitCdf.size() - 1) : 0u; s->dev.emitScale = emitScale;
     s->dev.neeScale = s->dEnv ? (float)(M_PI / 0.98 / ((double)d->envW * (double)d->envH)) : 0.f;
     memcpy(s->dev.skyColor, d->sky.color, 12); memcpy(s->dev.skyDir, d->sky.dir, 12); s->dev.skyIntensity = d->sky.intensity;
     s->dev.nNodes = (uint32_t)(s->hNodes.size() / 16); s->dev.nRefs = (uint32_t)bo.refTri.size();
@@ -416,6 +454,8 @@ void mipt_scene_destroy(mipt_scene* s) {
     if (s->dMats) hipFree(s->dMats);
     if (s->dEnv) hipFree(s->dEnv);
     if (s->dEnvCdf) hipFree(s->dEnvCdf);
+    if (s->dEmitTri) hipFree(s->dEmitTri);
+    if (s->dEmitCdf) hipFree(s->dEmitCdf);
     delete s;
 }
 
@@ -433,6 +473,12 @@ uint64_t mipt_scene_get_env_cdf(const mipt_scene* s, float* out, uint64_t cap) {
     if (!s) return 0;
     if (out && cap >= s->hEnvCdf.size()) memcpy(out, s->hEnvCdf.data(), s->hEnvCdf.size() * sizeof(float));
     return s->hEnvCdf.size();
+}
+uint64_t mipt_scene_get_emitters(const mipt_scene* s, float* tris, float* cdf, uint64_t cap_tris) {
+    if (!s) return 0;
+    const uint64_t n = s->hEmitTri.size() / 15;
+    if (tris && cdf && n && cap_tris >= n) { memcpy(tris, s->hEmitTri.data(), n * 15 * sizeof(float)); memcpy(cdf, s->hEmitCdf.data(), (n + 1) * sizeof(float)); }
+    return n;
 }
 int mipt_scene_bvh_was_cached(const mipt_scene* s) { return s && s->bvhFromCache ? 1 : 0; }
 
@@ -454,8 +500,8 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
     // env-map importance sampling: wave-stack integrator with node-keyed streams only, and only with an env map to sample
     const bool nee = t->estimator == 1;
     if (nee && (t->rngMode != MIPT_RNG_NODE || t->integrator != 0)) return fail(t, MIPT_E_INVALID, "estimator 1 needs integrator 0 and rng_mode node");
-    if (nee && !sc->dev.envCdf) return fail(t, MIPT_E_INVALID, "estimator 1 needs a scene with an environment map");
-    if (nee && npix >= (1u << 30)) return fail(t, MIPT_E_LIMIT, "viewport too large for estimator 1");
+    if (nee && !sc->dev.envCdf && !sc->dev.nEmit) return fail(t, MIPT_E_INVALID, "estimator 1 needs a scene with an environment map or emissive triangles");
+    if (nee && npix >= (1u << 29)) return fail(t, MIPT_E_LIMIT, "viewport too large for estimator 1");
 
     if (t->samplePixels < npix) {
         if (t->sample) hipFree(t->sample);
@@ -476,7 +522,7 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
         // depth-first integrator: no queues
     } else if (t->integrator == 0) {
         // persistent wave stacks: 256 entries per recursion level per wave (see k_wavestack), independent of the viewport
-        wcap = (nee ? 384u : 256u) * std::max<uint32_t>(D, 1u) + 256u;      // estimator 1: up to three rays per hit
+        wcap = (nee ? 512u : 256u) * std::max<uint32_t>(D, 1u) + 256u;      // estimator 1: up to four rays per hit
         const size_t need = (size_t)persistentBlocks * 4 * wcap;
         if (t->wstackEntries < need) {
             free_queue(t->wstack); t->wstackEntries = 0;

@@ -23,6 +23,9 @@ struct SceneDev {
     uint32_t wide;            // 0: BVH2 nodes, 1: quantised 4-wide nodes
     const float* envCdf;      // estimator 1: rowCdf[envH+1], then envH rows of colCdf[envW+1]; nullptr without an env map
     float neeScale;           // pi / (0.98 * envW * envH)
+    const float* emitTri;     // estimator 1: emissive triangles, 15 floats each [v0 e1 e2 unit-normal Le]; nullptr if none
+    const float* emitCdf;     // area CDF, nEmit + 1 entries
+    uint32_t nEmit; float emitScale;   // total emissive area / (2 pi 0.98)
 };
 
 // Per-frame constants computed once on the host (CUDATracerProg.cu:369-397 computes them per thread).

@@ -471,9 +471,10 @@ MIPT_DEV void load_ref(const float4* lds, const float4* glb, uint32_t i, float4&
 }
 
 // ---- env-map importance sampling (option "estimator" = 1; specification: include/mipt.h, tables built in api.hip) ----
-constexpr uint32_t kShadowBit = 0x80000000u;   // flags carried in the pixel word of a ray record (pixel index < 2^30)
+constexpr uint32_t kShadowBit = 0x80000000u;   // flags carried in the pixel word of a ray record (pixel index < 2^29)
 constexpr uint32_t kNoEnvBit  = 0x40000000u;   //   occlusion ray of the estimator / diffuse child whose miss adds nothing
-constexpr uint32_t kPixMask   = 0x3FFFFFFFu;
+constexpr uint32_t kNoEmitBit = 0x20000000u;   //   diffuse child that skips the emission of the surface it lands on
+constexpr uint32_t kPixMask   = 0x1FFFFFFFu;
 MIPT_DEV uint32_t cdf_find(const float* __restrict__ cdf, uint32_t n, float u) {     // largest i in [0,n-1] with cdf[i] <= u
     uint32_t lo = 0, hi = n;
     while (hi - lo > 1u) { uint32_t mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid; else hi = mid; }
@@ -496,6 +497,25 @@ MIPT_DEV bool sample_env(const SceneDev& S, float u1, float u2, v3& dir, v3& L, 
     const float* px = S.env + ((size_t)iv * W + iu) * 3;
     L = mk3(px[0], px[1], px[2]);
     wgt = st * S.neeScale / (pr * pc);
+    return true;
+}
+
+// one point on the emissive triangles, uniform by area, as seen from x (surface normal N); false when it adds nothing.
+// Lw = Le * p_cap / p_area * |cos_y| / dist^2, tmax = where the occlusion ray stops short of the emitter.
+MIPT_DEV bool sample_emitter(const SceneDev& S, float r0, float r1, float r2, v3 x, v3 N, v3& dir, v3& Lw, float& tmax) {
+    const uint32_t k = cdf_find(S.emitCdf, S.nEmit, r0);
+    const float* E = S.emitTri + (size_t)k * 15;
+    const float su = __builtin_sqrtf(r1), b1 = 1 - su, b2 = r2 * su;
+    v3 y = mk3(E[0], E[1], E[2]) + mk3(E[3], E[4], E[5]) * b1 + mk3(E[6], E[7], E[8]) * b2;
+    v3 w = y - x;
+    const float dist2 = dot3(w, w), dist = __builtin_sqrtf(dist2);
+    if (!(dist > 0.f)) return false;
+    dir = w / dist;
+    if (!(dot3(dir, N) > 0.02f)) return false;
+    const float cosy = __builtin_fabsf(dot3(mk3(E[9], E[10], E[11]), dir));
+    if (!(cosy > 0.f)) return false;
+    Lw = mk3(E[12], E[13], E[14]) * (cosy * S.emitScale / dist2);
+    tmax = dist * 0.9999f;
     return true;
 }
 
@@ -568,13 +588,15 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
             const bool has = lane < n;
             Bounce b;
             uint32_t spix = 0, snode = 0, ss0 = 0;
-            bool wantShadow = false, opaque = false; v3 sdir = mk3(0, 0, 1), scon = mk3(0, 0, 0);
+            bool wantEnv = false, wantEmit = false, opaque = false;
+            v3 sdir = mk3(0, 0, 1), scon = mk3(0, 0, 0), edir = mk3(0, 0, 1), econ = mk3(0, 0, 0); float etmax = 0.f;
             if (has) {
                 const uint32_t e = nF + lane;
                 v3 P = mk3(sq[0 * kSqCap + e], sq[1 * kSqCap + e], sq[2 * kSqCap + e]);
                 v3 sd = mk3(sq[3 * kSqCap + e], sq[4 * kSqCap + e], sq[5 * kSqCap + e]);
                 v3 sb = mk3(sq[6 * kSqCap + e], sq[7 * kSqCap + e], sq[8 * kSqCap + e]);
-                spix = sqi[9 * kSqCap + e] & (NEE ? kPixMask : 0xFFFFFFFFu); snode = sqi[10 * kSqCap + e]; ss0 = sqi[11 * kSqCap + e];
+                const uint32_t fpix = sqi[9 * kSqCap + e];
+                spix = fpix & (NEE ? kPixMask : 0xFFFFFFFFu); snode = sqi[10 * kSqCap + e]; ss0 = sqi[11 * kSqCap + e];
                 const float su = sq[12 * kSqCap + e], sv = sq[13 * kSqCap + e];
                 const uint32_t tf = sqi[14 * kSqCap + e];
                 const bool front = (tf >> 31) != 0;
@@ -585,40 +607,56 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 v3 hn = xyz(n0) * w0 + xyz(n1) * w1 + xyz(n2) * w2;
                 Surface sf; sf.P = P; sf.N = front ? hn : -hn; sf.mesh = __float_as_uint(n0.w);
                 Material mat = load_material(A.S, sf.mesh);
-                add_sample(A.sample, spix, sb * (mat.emissive * mat.emissiveStrength));
+                if (!(NEE && (fpix & kNoEmitBit))) add_sample(A.sample, spix, sb * (mat.emissive * mat.emissiveStrength));
                 Lcg rng; rng.state = node_seed(ss0, snode);
                 b = shade_hit(mat, sf, sd, front, rng);
                 b.f1 = sb * b.f1; b.f2 = sb * b.f2;
                 if constexpr (NEE) {
-                    // the environment seen through the diffuse cap is sampled explicitly: two more draws of this hit's
-                    // stream, one occlusion ray; the diffuse child is flagged so that its own miss adds nothing
+                    // what the diffuse child would find by chance -- the environment when it escapes, the emission of the
+                    // surface it lands on -- is sampled explicitly: further draws of this hit's stream (2 for the env map,
+                    // then 3 for the emitters), one occlusion ray each; the child is flagged to skip those terms itself
                     opaque = mat.opacity == 1.f;
-                    if (opaque) {
+                    if (opaque && A.S.envCdf) {
                         const float u1 = rng.NextFloat(), u2 = rng.NextFloat();
                         v3 L; float wgt;
-                        if (sample_env(A.S, u1, u2, sdir, L, wgt) && dot3(sdir, sf.N) > 0.02f) { wantShadow = true; scon = b.f2 * (L * wgt); }
+                        if (sample_env(A.S, u1, u2, sdir, L, wgt) && dot3(sdir, sf.N) > 0.02f) { wantEnv = true; scon = b.f2 * (L * wgt); }
+                    }
+                    if (opaque && A.S.nEmit) {
+                        const float r0 = rng.NextFloat(), r1 = rng.NextFloat(), r2 = rng.NextFloat();
+                        v3 Lw;
+                        if (sample_emitter(A.S, r0, r1, r2, b.o2, sf.N, edir, Lw, etmax)) { wantEmit = true; econ = b.f2 * Lw; }
                     }
                 }
             }
-            const unsigned long long sm = NEE ? __ballot(wantShadow) : 0ull;
-            const uint32_t total = 2u * n + (uint32_t)__popcll(sm);
+            const unsigned long long sm = NEE ? __ballot(wantEnv) : 0ull, em = NEE ? __ballot(wantEmit) : 0ull;
+            const uint32_t nEnvRays = (uint32_t)__popcll(sm);
+            const uint32_t total = 2u * n + nEnvRays + (uint32_t)__popcll(em);
             if (sp + total > A.cap) {
                 if (lane == 0) atomicOr(A.stats + 39, 1ull);       // overflow: reported by the host, never written past
             } else {
                 if (has) {
                     const uint32_t w = sp + 2u * lane;
+                    uint32_t flags2 = 0;
+                    if (NEE && opaque) flags2 = (A.S.envCdf ? kNoEnvBit : 0u) | (A.S.nEmit ? kNoEmitBit : 0u);
                     qa[w] = make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x);
                     qb[w] = make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y);
                     qc[w] = make_float4(b.f1.z, __uint_as_float(spix), __uint_as_float(snode * 2u), __uint_as_float(ss0));
                     qa[w + 1] = make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x);
                     qb[w + 1] = make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y);
-                    qc[w + 1] = make_float4(b.f2.z, __uint_as_float(spix | (NEE && opaque ? kNoEnvBit : 0u)), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0));
+                    qc[w + 1] = make_float4(b.f2.z, __uint_as_float(spix | flags2), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0));
                 }
-                if (NEE && wantShadow) {
+                // occlusion rays: the record's node word carries tmax (+inf towards the environment)
+                if (NEE && wantEnv) {
                     const uint32_t w = sp + 2u * n + (uint32_t)__popcll(sm & below);
                     qa[w] = make_float4(b.o2.x, b.o2.y, b.o2.z, sdir.x);
                     qb[w] = make_float4(sdir.y, sdir.z, scon.x, scon.y);
-                    qc[w] = make_float4(scon.z, __uint_as_float(spix | kShadowBit), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0));
+                    qc[w] = make_float4(scon.z, __uint_as_float(spix | kShadowBit), __builtin_inff(), __uint_as_float(ss0));
+                }
+                if (NEE && wantEmit) {
+                    const uint32_t w = sp + 2u * n + nEnvRays + (uint32_t)__popcll(em & below);
+                    qa[w] = make_float4(b.o2.x, b.o2.y, b.o2.z, edir.x);
+                    qb[w] = make_float4(edir.y, edir.z, econ.x, econ.y);
+                    qc[w] = make_float4(econ.z, __uint_as_float(spix | kShadowBit), etmax, __uint_as_float(ss0));
                 }
                 sp += total;
             }
@@ -638,7 +676,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 if (tf == 0xFFFFFFFFu) {
                     if (shadow) add_sample(A.sample, spix, sb);                  // unoccluded: the pre-weighted environment term
                     else if (!noEnv) add_sample(A.sample, spix, sb * on_miss(A.S, sd));
-                } else if (!shadow) {
+                } else if (!shadow && !(NEE && (fpix & kNoEmitBit))) {
                     const uint32_t mesh = __float_as_uint(A.S.shade[(size_t)(tf & 0x7FFFFFFFu) * 3].w);
                     Material mat = load_material(A.S, mesh);
                     add_sample(A.sample, spix, sb * (mat.emissive * mat.emissiveStrength));
@@ -679,7 +717,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     cur = 0;
                     active = true;
                     traced++;
-                    if constexpr (NEE) if (pix & kShadowBit) shadowTraced++;
+                    if constexpr (NEE) if (pix & kShadowBit) { shadowTraced++; h.t = __uint_as_float(node); }    // stops short of the emitter
                     if (A.pixelRays) atomicAdd(A.pixelRays + (pix & (NEE ? kPixMask : 0xFFFFFFFFu)), 1u);
                 }
             }

@@ -119,12 +119,19 @@ int  mipt_scene_bvh_was_cached(const mipt_scene*);
  *       p_env ~ (r+g+b) * sin(theta) per texel (two more draws of the hit's stream, after the cone draws; texel by CDF
  *       inversion, uniform inside the texel) and, if it lies inside the diffuse cap (dot(dir, N) > 0.02) and one
  *       occlusion ray from the child's origin finds nothing, adds  beta * albedo * rt * L_texel * p_cap / p_env  with
- *       p_cap = 1 / (2 pi 0.98).  Same expectation as estimator 0, far less variance under a small bright sun.
- *       Occlusion rays are counted in mipt_counters.shadow_rays (and in .rays).  Needs an env map, integrator 0 and
- *       rng_mode node.
+ *       p_cap = 1 / (2 pi 0.98).  Emissive triangles likewise: the diffuse child skips the emission of the surface it
+ *       lands on; one point y is drawn uniformly by area on the emissive triangles (three more draws: triangle by area
+ *       CDF, then b1 = 1 - sqrt(r1), b2 = r2 sqrt(r1)) and, if its direction lies inside the cap and an occlusion ray
+ *       stopping at 0.9999 of the distance finds nothing, adds  beta * albedo * rt * Le * |cos_y| / dist^2 * A_total * p_cap
+ *       (emission is two-sided in the reference, CUDATracerProg.cu:528, hence |cos|).  Same expectation as estimator 0,
+ *       far less variance under a small bright sun or lamp.  Occlusion rays are counted in mipt_counters.shadow_rays
+ *       (and in .rays).  Acts on whichever of env map / emissive triangles the scene has (error if neither); needs
+ *       integrator 0 and rng_mode node.
  * Sampling tables of estimator 1 (rowCdf[envH+1], then envH rows of colCdf[envW+1]); returns the float count,
  * 0 without an env map.  No counterpart in the reference (it has no light sampling). */
-uint64_t mipt_scene_get_env_cdf(const mipt_scene*, float* out, uint64_t cap);          /* 1 if the BVH came from desc.bvhCachePath, 0 if it was built */
+uint64_t mipt_scene_get_env_cdf(const mipt_scene*, float* out, uint64_t cap);
+/* emitter table of estimator 1: n x 15 floats [v0 e1 e2 unit-normal Le] and the area CDF [n+1]; returns n */
+uint64_t mipt_scene_get_emitters(const mipt_scene*, float* tris, float* cdf, uint64_t cap_tris);          /* 1 if the BVH came from desc.bvhCachePath, 0 if it was built */
 
 /* ---- the hot path: PathTracer::Trace (CUDATracer.hpp:352-358; CUDATracerProg.cu:937-963) -------------------
  * One sample per pixel for sample index settings->frameID, folded into acc_dev (w*h*4 floats, running mean with

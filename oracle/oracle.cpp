@@ -415,6 +415,8 @@ struct orc_scene {
     int estimator = 0;
     std::vector<float> envCdf;       // rowCdf[H+1], then H x colCdf[W+1]
     float neeScale = 0.f;            // pi / (0.98 * W * H): p_cap * texel solid angle / sin(theta)
+    // emissive triangles (estimator 1): 15 floats each [v0 e1 e2 n Le], area CDF [n+1], total area / (2 pi 0.98)
+    std::vector<float> emitTri, emitCdf; float emitScale = 0.f;
 };
 
 namespace {
@@ -689,6 +691,36 @@ void build_env_cdf(orc_scene& s) {
     row[H] = 1.0f;
     s.neeScale = (float)(M_PI / 0.98 / ((double)W * (double)H));
 }
+// Emitter table: every triangle (global id order) of a mesh with emissiveStrength > 0 and a non-black emissive colour
+// and a non-zero area.  In double from the float vertices: c = cross(e1, e2), area = 0.5 |c|, unit normal = c / |c|;
+// CDF = running area / total area, as float.  Le = emissiveColor * emissiveStrength (float).
+void build_emitters(orc_scene& s) {
+    s.emitTri.clear(); s.emitCdf.clear(); s.emitScale = 0.f;
+    std::vector<double> area;
+    for (const OMesh& m : s.meshes) {
+        const orc_material& mt = m.mat;
+        if (!(mt.emissiveStrength > 0.f) || !(mt.emissiveColor[0] > 0.f || mt.emissiveColor[1] > 0.f || mt.emissiveColor[2] > 0.f)) continue;
+        const uint32_t nt = (uint32_t)m.idx.size() / 3;
+        for (uint32_t t = 0; t < nt; t++) {
+            v3 v0, e1, e2; tri_of(m, t, &v0, &e1, &e2);
+            const double cx = (double)e1.y * e2.z - (double)e2.y * e1.z, cy = (double)e1.z * e2.x - (double)e2.z * e1.x,
+                         cz = (double)e1.x * e2.y - (double)e2.x * e1.y;
+            const double len = sqrt(cx * cx + cy * cy + cz * cz);
+            if (!(len > 0.0)) continue;
+            const float rec[15] = { v0.x, v0.y, v0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z, (float)(cx / len), (float)(cy / len), (float)(cz / len),
+                                    mt.emissiveColor[0] * mt.emissiveStrength, mt.emissiveColor[1] * mt.emissiveStrength, mt.emissiveColor[2] * mt.emissiveStrength };
+            s.emitTri.insert(s.emitTri.end(), rec, rec + 15);
+            area.push_back(0.5 * len);
+        }
+    }
+    if (area.empty()) return;
+    double total = 0.0; for (double a : area) total += a;
+    s.emitCdf.resize(area.size() + 1);
+    double run = 0.0;
+    for (size_t i = 0; i <= area.size(); i++) { s.emitCdf[i] = (float)(run / total); if (i < area.size()) run += area[i]; }
+    s.emitCdf[area.size()] = 1.0f;
+    s.emitScale = (float)(total / (2.0 * M_PI * 0.98));
+}
 // largest i in [0, n-1] with cdf[i] <= u  (cdf[0] = 0, cdf[n] = 1 > u)
 inline uint32_t cdf_find(const float* cdf, uint32_t n, float u) {
     uint32_t lo = 0, hi = n;
@@ -737,7 +769,25 @@ v3 OnMiss(const Ctx& k, v3 d) {                                // :796-846
     v3 p1 = (dv) * p00 + (1 - dv) * p00;
     return du * p1 + (1 - du) * p0;
 }
-v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noEnv = false) {   // :426-541
+// one point on the emissive triangles as seen from x (normal N); false when it adds nothing
+inline bool sample_emitter(const orc_scene& s, float r0, float r1, float r2, v3 x, v3 N, v3* dir, v3* Lw, float* tmax) {
+    const uint32_t n = (uint32_t)s.emitCdf.size() - 1;
+    const uint32_t k = cdf_find(s.emitCdf.data(), n, r0);
+    const float* E = &s.emitTri[(size_t)k * 15];
+    const float su = sqrtf(r1), b1 = 1 - su, b2 = r2 * su;
+    v3 y = ld3(E) + ld3(E + 3) * b1 + ld3(E + 6) * b2;
+    v3 w = y - x;
+    const float dist2 = dot3(w, w), dist = sqrtf(dist2);
+    if (!(dist > 0.f)) return false;
+    *dir = w / dist;
+    if (!(dot3(*dir, N) > 0.02f)) return false;
+    const float cosy = fabsf(dot3(ld3(E + 9), *dir));
+    if (!(cosy > 0.f)) return false;
+    *Lw = ld3(E + 12) * (cosy * s.emitScale / dist2);
+    *tmax = dist * 0.9999f;
+    return true;
+}
+v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noEnv = false, bool noEmit = false) {   // :426-541
     v3 color = mk(0, 0, 0);
     if (ttl <= 0) return color;
     k.pixel_rays++;
@@ -787,10 +837,12 @@ v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noE
         d2 = RandDirInsideCone(*rng, N, 0.49f, *k.M);
         o2 = P + N * 1e-6f;
     }
-    // estimator 1: the environment seen by the diffuse child is sampled explicitly (one occlusion ray) instead
-    const bool nee = k.s->estimator == 1 && k.rng_mode == ORC_RNG_NODE && !k.s->envCdf.empty() && mat.opacity == 1.f && ttl - 1 > 0;
-    c = LaunchRayRecur(k, o2, d2, ttl - 1, dfs, node * 2 + 1, nee);    // :525
-    if (nee) {
+    // estimator 1: what the diffuse child would find by chance -- the environment when it escapes, the emission of the
+    // surface it lands on -- is sampled explicitly instead (one occlusion ray each); the child is told to skip those terms
+    const bool nee = k.s->estimator == 1 && k.rng_mode == ORC_RNG_NODE && mat.opacity == 1.f && ttl - 1 > 0;
+    const bool neeEnv = nee && !k.s->envCdf.empty(), neeEmit = nee && !k.s->emitCdf.empty();
+    c = LaunchRayRecur(k, o2, d2, ttl - 1, dfs, node * 2 + 1, neeEnv, neeEmit);    // :525
+    if (neeEnv) {
         float u1 = rng->NextFloat(), u2 = rng->NextFloat();
         v3 wdir, L; float wgt;
         if (sample_env(*k.s, *k.M, u1, u2, &wdir, &L, &wgt) && dot3(wdir, N) > 0.02f) {
@@ -799,8 +851,17 @@ v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noE
             if (sh.tri < 0) c = c + L * wgt;
         }
     }
+    if (neeEmit) {
+        float r0 = rng->NextFloat(), r1 = rng->NextFloat(), r2 = rng->NextFloat();
+        v3 wdir, Lw; float tmax;
+        if (sample_emitter(*k.s, r0, r1, r2, o2, N, &wdir, &Lw, &tmax)) {
+            k.pixel_rays++; k.c->shadow++;
+            Hit sh = isect(*k.s, k.isect, o2, wdir, k.c);
+            if (!(sh.tri >= 0 && sh.t < tmax)) c = c + Lw;
+        }
+    }
     color = color + col * c * rt * ((mat.opacity == 1.f) ? 1.f : (1 - mat.opacity));   // :526
-    color = color + ld3(mat.emissiveColor) * mat.emissiveStrength;                     // :528
+    if (!noEmit) color = color + ld3(mat.emissiveColor) * mat.emissiveStrength;        // :528
     return color;
 }
 struct CamPre { float pixelSize, origin_x, origin_y; };
@@ -912,6 +973,7 @@ orc_scene* orc_scene_create(const orc_scene_desc* d) {
         base += nt;
         s->meshes.push_back(std::move(m));
     }
+    build_emitters(*s);
     return s;
 }
 void orc_scene_destroy(orc_scene* s) { delete s; }
@@ -927,6 +989,11 @@ int orc_scene_set_estimator(orc_scene* s, int e) { if (e != 0 && e != 1) return 
 uint64_t orc_scene_get_env_cdf(const orc_scene* s, float* out, uint64_t cap) {
     if (out && cap >= s->envCdf.size()) memcpy(out, s->envCdf.data(), s->envCdf.size() * sizeof(float));
     return s->envCdf.size();
+}
+uint64_t orc_scene_get_emitters(const orc_scene* s, float* tris, float* cdf, uint64_t cap_tris) {
+    const uint64_t n = s->emitTri.size() / 15;
+    if (tris && cdf && cap_tris >= n && n) { memcpy(tris, s->emitTri.data(), n * 15 * sizeof(float)); memcpy(cdf, s->emitCdf.data(), (n + 1) * sizeof(float)); }
+    return n;
 }
 int orc_scene_set_flat_width(orc_scene* s, uint32_t width) {
     if (width != 2 && width != 4) return 1;

@@ -115,11 +115,16 @@ int orc_trace_rays(const orc_scene*, int isect, const float* origins, const floa
  *   1 = env-map importance sampling at opaque hits: the diffuse child no longer collects the environment when it
  *       misses; instead one direction is drawn from the environment map's luminance x sin(theta) distribution
  *       (two extra draws of the hit's stream, after the cone draws) and, if it lies inside the diffuse cap
- *       (cos > 0.02) and is unoccluded, adds  albedo * rt * L * p_cap / p_env.  Same expectation as estimator 0.
- * Requires an env map and RNG_NODE; ignored otherwise. */
+ *       (cos > 0.02) and is unoccluded, adds  albedo * rt * L * p_cap / p_env.  Likewise for emissive triangles:
+ *       the diffuse child skips the emission of the surface it lands on, and one point is drawn uniformly by area on
+ *       the emissive triangles (three more draws) and connected with an occlusion ray.  Same expectation as estimator 0.
+ * Acts on whichever of env map / emissive triangles the scene has; needs RNG_NODE; ignored otherwise. */
 int orc_scene_set_estimator(orc_scene*, int estimator);
 /* the sampling tables of estimator 1: rowCdf[H+1] then H rows of colCdf[W+1]; returns the float count (0 = no env map) */
 uint64_t orc_scene_get_env_cdf(const orc_scene*, float* out, uint64_t cap);
+
+/* emitter table of estimator 1: n x 15 floats [v0 e1 e2 unit-normal Le] and the area CDF [n+1]; returns n */
+uint64_t orc_scene_get_emitters(const orc_scene*, float* tris, float* cdf, uint64_t cap_tris);
 
 int orc_render(const orc_scene*, const orc_settings* s, int isect, int rng_mode, int math_mode,
                uint32_t first_frame, uint32_t n_frames, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,

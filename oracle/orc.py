@@ -86,6 +86,8 @@ lib.orc_scene_set_flat_width.argtypes = [_vp, C.c_uint32]
 lib.orc_scene_set_estimator.argtypes = [_vp, C.c_int]
 lib.orc_scene_get_env_cdf.argtypes = [_vp, _vp, C.c_uint64]
 lib.orc_scene_get_env_cdf.restype = C.c_uint64
+lib.orc_scene_get_emitters.argtypes = [_vp, _vp, _vp, C.c_uint64]
+lib.orc_scene_get_emitters.restype = C.c_uint64
 lib.orc_trace_rays.argtypes = [_vp, C.c_int, _vp, _vp, C.c_uint32, _vp, C.POINTER(Stats), C.c_int]
 lib.orc_render.argtypes = [_vp, C.POINTER(Settings), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(Stats), C.c_int]
@@ -183,6 +185,13 @@ class Scene:
         out = np.zeros(n, np.float32)
         lib.orc_scene_get_env_cdf(self.h, _ptr(out), n)
         return out
+
+    def emitters(self):
+        n = lib.orc_scene_get_emitters(self.h, None, None, 0)
+        tris, cdf = np.zeros((n, 15), np.float32), np.zeros(n + 1 if n else 0, np.float32)
+        if n:
+            lib.orc_scene_get_emitters(self.h, _ptr(tris), _ptr(cdf), n)
+        return tris, cdf
 
     def check_flat_bvh(self):
         buf = C.create_string_buffer(256)

@@ -338,22 +338,38 @@ def test_dfs_order_integrator_is_bit_identical_to_the_oracle(tracer, ptlib, orac
         tracer.free(acc), tracer.free(ldr)
 
 
-@pytest.mark.parametrize("width", [2, 4], ids=["bvh2", "q4"])
-def test_env_importance_sampling_estimator_matches_oracle(tracer, ptlib, oracle, width):
-    """option estimator = 1 (include/mipt.h): identical ray trees incl. the occlusion rays, radiance to the usual
-    tolerance, and the shadow-ray counter equals the oracle's."""
+def _light_sampling_scene(ptlib, kind):
     rng = np.random.default_rng(3)
     env = (rng.uniform(0.2, 1.0, (32, 64, 3)) ** 2).astype(np.float32)
     env[6:9, 10:14] = 40.0
     env[20:, :5] = 0.0
+    if kind == "env":
+        return ptlib.builtin_scene(1, env), ptlib.DEFAULT_CAMERA
+    if kind == "emitters":
+        return ptlib.builtin_scene(0), ptlib.CORNELL_CAMERA
+    # both: the default scene under the env map with a small two-sided lamp (one quad) hanging above it
     data = ptlib.builtin_scene(1, env)
+    v = np.zeros(4, ptlib.VERTEX_DTYPE)
+    v["position"] = [(-0.3, 2.2, -0.3), (-0.3, 2.2, 0.3), (0.3, 2.2, 0.3), (0.3, 2.2, -0.3)]
+    v["normal"] = (0, -1, 0)
+    lamp = (v, np.array([0, 1, 2, 0, 2, 3], np.uint32), ptlib.make_material(color=(1, 1, 1), emissive=(1.0, 0.9, 0.7), strength=25.0))
+    return ptlib.SceneData(data.meshes + [lamp], data.sky, env), ptlib.DEFAULT_CAMERA
+
+
+@pytest.mark.parametrize("kind,width", [("env", 2), ("env", 4), ("emitters", 0), ("both", 4)])
+def test_light_sampling_estimator_matches_oracle(tracer, ptlib, oracle, kind, width):
+    """option estimator = 1 (include/mipt.h): env-map importance sampling and/or emissive-triangle sampling.  Identical
+    ray trees incl. the occlusion rays, radiance to the usual tolerance, the shadow-ray counter equals the oracle's."""
+    data, cam_kw = _light_sampling_scene(ptlib, kind)
     sc = ptlib.Scene(tracer, data, node_width=width)
     o = oracle.Scene(data)
     o.set_flat_bvh(*sc.flat())
     o.set_estimator(1)
     assert np.array_equal(sc.env_cdf().view(np.uint32), o.env_cdf().view(np.uint32))
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(sc.emitters(), o.emitters()))
+    assert (len(sc.env_cdf()) > 0) == (kind != "emitters") and (len(sc.emitters()[0]) > 0) == (kind != "env")
     w, h, depth = 112, 80, 6
-    s = ptlib.make_settings(ptlib.make_camera(**ptlib.DEFAULT_CAMERA), w, h, depth)
+    s = ptlib.make_settings(ptlib.make_camera(**cam_kw), w, h, depth)
     acc, ldr = dev_buffers(tracer, w, h)
     tracer.set_option("estimator", 1)
     tracer.set_option("count_pixel_rays", 1)
@@ -378,10 +394,11 @@ def test_env_importance_sampling_estimator_matches_oracle(tracer, ptlib, oracle,
         s.frameID = 0
         tracer.trace(sc, s, acc, ldr)
         assert tracer.counters().shadow_rays == 0
-        # needs an env map, node-keyed streams and the wave-stack integrator
+        # needs something to sample, node-keyed streams and the wave-stack integrator
         tracer.set_option("estimator", 1)
+        dark = ptlib.builtin_scene(1)                      # no env map, no emissive mesh
         with pytest.raises(ptlib.MiptError):
-            tracer.trace(ptlib.Scene(tracer, ptlib.builtin_scene(0)), s, acc, ldr)
+            tracer.trace(ptlib.Scene(tracer, dark), s, acc, ldr)
         tracer.set_option("integrator", 1)
         with pytest.raises(ptlib.MiptError):
             tracer.trace(sc, s, acc, ldr)

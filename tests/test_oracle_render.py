@@ -164,3 +164,26 @@ def test_env_importance_sampling_keeps_the_expectation(ptlib, oracle):
     o.set_estimator(0)
     b = o.render(s, oracle.ISECT_FLAT, oracle.RNG_DFS, oracle.MATH_DET, 0, 1, want_ldr=False)
     assert np.array_equal(a["acc"], b["acc"]) and a["stats"].shadow_rays == 0
+
+
+def test_emitter_sampling_keeps_the_expectation_on_the_cornell_box(ptlib, oracle):
+    # estimator 1 on a scene lit by emissive triangles only: the light quad is sampled by area with an occlusion ray
+    # and the diffuse child skips the emission of whatever it lands on; the emitter tables are built twice, independently
+    data = ptlib.builtin_scene(0)
+    sc = ptlib.Scene(None, data)
+    o = oracle.Scene(data)
+    (ta, ca), (tb, cb) = sc.emitters(), o.emitters()
+    assert len(ta) == 2 and np.array_equal(ta.view(np.uint32), tb.view(np.uint32)) and np.array_equal(ca, cb)
+    assert np.allclose(ca, (0, 0.5, 1)) and np.allclose(ta[:, 12:15], (10, 8, 5)) and np.allclose(np.abs(ta[:, 10]), 1)
+    assert len(ptlib.Scene(None, ptlib.builtin_scene(1)).emitters()[0]) == 0
+    o.set_flat_bvh(*sc.flat())
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), 48, 32, 4)
+    imgs, stats = [], []
+    for est in (0, 1):
+        o.set_estimator(est)
+        r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, 300, want_ldr=False)
+        imgs.append(r["acc"][..., :3].astype(np.float64)); stats.append(r["stats"])
+    assert stats[0].shadow_rays == 0 and 0 < stats[1].shadow_rays < stats[1].rays
+    assert abs(imgs[1].mean() / imgs[0].mean() - 1) < 0.03
+    blocks = [im.reshape(2, 16, 3, 16, 3).mean((1, 3)) for im in imgs]
+    assert np.abs(blocks[1] / blocks[0] - 1).mean() < 0.08
