@@ -185,7 +185,7 @@ def main():
     if rank == 0:
         nn, nr = (len(x) for x in sc.bvh())
         if a.integrator == 0:    # one k_wavestack launch per frame traces every ray of the frame
-            lds = sc.bvh_width == 2 and nn * 4 + nr * 3 <= 256 and not a.estimator          # <LDS scene, 4-wide nodes, light sampling>
+            lds = sc.bvh_width == 2 and nn * 4 + nr * 3 <= 256          # <LDS scene, 4-wide nodes, light sampling>
             kernel_name = "mipt::k_wavestack<%s, %s, %s>" % tuple("true" if x else "false" for x in (lds, sc.bvh_width == 4, bool(a.estimator)))
             sec_rays, sec_ms, sec_launches = float(cnt.rays), prof.ms[0], prof.launches[0]
         else:                    # k_level<false,*> launches carry the non-primary levels

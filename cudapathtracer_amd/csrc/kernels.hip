@@ -827,9 +827,10 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
 }
 
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
-    const bool lds = !a.S.wide && !a.nee && a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec;
+    const bool lds = !a.S.wide && a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec;
     if (a.nee) {
         if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
         else hipLaunchKernelGGL((k_wavestack<false, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
     }
     else if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false>), dim3(blocks), dim3(kBlock), 0, s, a);
