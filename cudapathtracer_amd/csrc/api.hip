@@ -568,8 +568,11 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
         } else if (t->integrator == 0 && D >= 1) {
             HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), t->stream));
             StackArgs SA;
-            SA.S = sc->dev; SA.F = A.F; SA.stack = t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes; // auto: 8 for an LDS-resident scene, 24 otherwise (measured optima, profiles/r1/exp_min_descend.log)
-            SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (!sc->dev.wide && sc->dev.nNodes * 4 + sc->dev.nRefs * 3 <= 256 ? 8 : 24)); SA.pixCounter = t->counts; SA.nee = nee ? 1u : 0u;
+            SA.S = sc->dev; SA.F = A.F; SA.stack = t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes;
+            // min_descend_lanes auto: 8 for an LDS-resident scene, 24 otherwise (measured optima, profiles/r1/exp_min_descend.log)
+            const bool ldsScene = !sc->dev.wide && sc->dev.nNodes * 4 + sc->dev.nRefs * 3 <= 256;
+            SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (ldsScene ? 8 : 24));
+            SA.pixCounter = t->counts; SA.nee = nee ? 1u : 0u;
             SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npix;
             mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
             if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, t->stream)); }

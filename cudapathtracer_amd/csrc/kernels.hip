@@ -1,9 +1,13 @@
 // kernels.hip -- gfx950 kernels of the path-tracing core.
 //
-// Replaces the reference's single megakernel `GenRay` (CUDATracer/CUDATracerProg/CUDATracerProg.cu:859-922) with a
-// wavefront integrator: one launch per recursion level, each lane traces one queued ray through the flat BVH2,
-// shades the hit and appends up to two child rays to the next level's queue with a wave64 ballot/prefix compaction
-// (one atomic per wave).  Radiance is carried top-down as a throughput weight, so no return values flow back up
+// Replaces the reference's single megakernel `GenRay` (CUDATracer/CUDATracerProg/CUDATracerProg.cu:859-922):
+//   k_wavestack  the default integrator: persistent waves, each with a private LIFO of pending rays in HBM, in-wave
+//                refill of idle lanes, a two-ended LDS shade queue and dense shade batches; one launch per frame.
+//                Template flags: scene traversed from LDS, quantised 4-wide nodes, light-sampling estimator.
+//   k_level      the first design, one launch per recursion level with global ping-pong queues (integrator = 1)
+//   k_dfs        one lane per pixel-sample in the reference's depth-first order (rng_mode = dfs), bit-identical to it
+//   k_accumulate / k_tonemap / k_trace_rays / k_test_math
+// In the queue-based integrators radiance is carried top-down as a throughput weight, so no return values flow back up
 // the recursion tree (the reference's recursion, CUDATracerProg.cu:426-541, is linear in the children's radiance).
 //
 // Per-function reference lines are cited inline.  Arithmetic contract: see device_math.h.
