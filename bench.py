@@ -202,6 +202,7 @@ def main():
             if a.integrator == 0:
                 n_node, n_tri, miss = cpu["n_node_all"], cpu["n_tri_all"], cpu["miss_all"]
         traffic = a.traffic_gb
+        pmc = {}
         default_size = (W, H) == ((3840, 2160) if a.workload == "grid" else (1920, 1080)) and (a.workload != "grid" or a.grid_n == 2236)
         if traffic is None and a.integrator == 0 and default_size and not a.depth and not a.node_width and not a.estimator:
             # HBM bytes per launch from the committed PMC passes of this same command (scripts/pmc_passes.sh;
@@ -209,6 +210,7 @@ def main():
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")))
                 traffic = round(pj[a.workload]["hbm_gb_per_launch"], 2)
+                pmc = {k: pj[a.workload][k] for k in ("valu_busy", "lane_utilisation", "wait_frac", "l2_hit") if k in pj[a.workload]}
             except Exception:
                 traffic = None
         roof = None
@@ -223,6 +225,8 @@ def main():
                     "n_tri_per_ray": round(n_tri, 3), "rays_per_launch": round(sec_rays / max(sec_launches, 1), 1),
                     "avg_launch_ms": round(sec_ms / max(sec_launches, 1), 4), "launches": int(sec_launches),
                     "working_set_mb": round((nn * 64 + nr * 48) / 1e6, 2),
+                    # issue-side PMC figures of the same command (profiles/r1, scripts/pmc_to_json.py): what binds when HBM does not
+                    "pmc": pmc or None,
                     "note": ("working set (BVH+triangles) is cache/LDS resident for this workload: algorithmic bytes are served on-chip, so frac is not an HBM utilisation"
                              if (nn * 64 + nr * 48) < 32e6 else
                              "working set exceeds the 32 MB of L2; algorithmic bytes above `traffic` are re-reads served by L2 / Infinity Cache")}

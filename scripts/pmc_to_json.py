@@ -1,17 +1,34 @@
-"""Turns the tcc1/tcc2 passes of scripts/pmc_passes.sh into profiles/<round>/pmc_traffic.json (HBM bytes per launch of
-the dominant kernel).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B
-(MI355X_MICROARCH.md, HBM section), so fetched bytes are doubled before they are added to the written bytes."""
+"""Turns the passes of scripts/pmc_passes.sh into profiles/<round>/pmc_traffic.json: per workload, for the dominant kernel
+(k_wavestack), HBM bytes per launch and the issue-side figures bench.py reports next to the HBM roofline.
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B (MI355X_MICROARCH.md, HBM
+section), so fetched bytes are doubled before they are added to the written bytes.
+valu_busy = 4 * SQ_ACTIVE_INST_VALU / (SIMDs * cycles), cycles = GRBM_GUI_ACTIVE / 8 XCDs, 1024 SIMDs (a wave64 VALU
+instruction occupies its SIMD for four cycles); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU);
+wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES; l2_hit = TCC_HIT / (TCC_HIT + TCC_MISS).
+usage: pmc_to_json.py out.json tag=pass_root [tag=pass_root ...]"""
 import csv, glob, json, os, sys
+from collections import defaultdict
 out = {}
 for tag, root in (a.split("=") for a in sys.argv[2:]):
-    tot, n = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}, {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
-    for f in glob.glob(os.path.join(root, "tcc*", "*counter_collection.csv")):
+    tot, n = defaultdict(float), defaultdict(int)
+    for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if "k_wavestack" in r["Kernel_Name"] and r["Counter_Name"] in tot:
+            if "k_wavestack" in r["Kernel_Name"]:
                 tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
-    launches = max(n["FETCH_SIZE"], 1)
-    out[tag] = {"kernel": "mipt::k_wavestack", "launches": launches,
-                "fetch_size_kib_per_launch": tot["FETCH_SIZE"] / launches, "write_size_kib_per_launch": tot["WRITE_SIZE"] / max(n["WRITE_SIZE"], 1),
-                "hbm_gb_per_launch": (2 * tot["FETCH_SIZE"] / launches + tot["WRITE_SIZE"] / max(n["WRITE_SIZE"], 1)) * 1024 / 1e9}
+    per = lambda c: tot[c] / max(n[c], 1)          # per launch
+    e = {"kernel": "mipt::k_wavestack", "launches": max(n["FETCH_SIZE"], 1),
+         "fetch_size_kib_per_launch": per("FETCH_SIZE"), "write_size_kib_per_launch": per("WRITE_SIZE"),
+         "hbm_gb_per_launch": (2 * per("FETCH_SIZE") + per("WRITE_SIZE")) * 1024 / 1e9}
+    if n["SQ_ACTIVE_INST_VALU"] and n["GRBM_GUI_ACTIVE"]:
+        cycles = per("GRBM_GUI_ACTIVE") / 8
+        e["valu_busy"] = round(4 * per("SQ_ACTIVE_INST_VALU") / (1024 * cycles), 3)
+        e["lane_utilisation"] = round(per("SQ_THREAD_CYCLES_VALU") / (64 * per("SQ_ACTIVE_INST_VALU")), 3)
+        e["valu_wave_instructions_per_launch"] = per("SQ_INSTS_VALU")
+    if n["SQ_WAVE_CYCLES"]:
+        e["wait_frac"] = round(per("SQ_WAIT_ANY") / per("SQ_WAVE_CYCLES"), 3)
+    if n["TCC_HIT_sum"] and n["TCC_MISS_sum"]:
+        e["l2_hit"] = round(per("TCC_HIT_sum") / (per("TCC_HIT_sum") + per("TCC_MISS_sum")), 3)
+    out[tag] = e
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -101,7 +101,8 @@ def test_golden_render_crop(tracer, ptlib, oracle, name):
 
 
 @pytest.mark.parametrize("integrator,width", [(0, 2), (1, 2), (0, 4), (1, 4)], ids=["wavestack", "levelqueues", "wavestack-q4", "levelqueues-q4"])
-@pytest.mark.parametrize("name,w,h,depth", [("cornell", 160, 96, 5), ("default", 128, 128, 7), ("cornell", 67, 33, 1), ("default", 64, 64, 12)])
+@pytest.mark.parametrize("name,w,h,depth", [("cornell", 160, 96, 5), ("default", 128, 128, 7), ("cornell", 67, 33, 1), ("default", 64, 64, 12),
+                                            ("cornell", 1, 1, 3), ("cornell", 5, 3, 14), ("default", 3, 7, 16)])
 def test_frame_matches_oracle(tracer, ptlib, oracle, name, w, h, depth, integrator, width):
     which, cam_kw, env, _, _ = MG.CONFIGS[name]
     data = MG.scene_data(name)
