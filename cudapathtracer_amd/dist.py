@@ -29,3 +29,36 @@ def reduce_accumulation(acc, n_frames_total, dst=0, group=None):
     out = acc * (1.0 / float(n_frames_total))
     out[..., 3] = 1.0
     return out
+
+
+def render_progressive(render_frames, acc, first_frame, n_frames, rank, world, preview_every=0, on_preview=None, dst=0,
+                       group=None, to_reduce=lambda t: t):
+    """Sample-strided render with an optional progressive preview ("periodic reduce every K frames").
+
+    render_frames(first, count, stride) must ADD `count` frames (indices first, first+stride, ...) to this rank's SUM
+    buffer `acc` and return only when they are in it -- with libmipt: `tracer.render(scene, settings, first, count,
+    acc_ptr, None, stride, 1); tracer.synchronize()`.  The job is walked in rounds of `preview_every` global frames
+    (0 = one round); after every round but the last a COPY of the sum buffers is reduced onto `dst`, which receives
+    on_preview(mean_image, frames_done); the private sums keep growing, so the final reduce_accumulation is exact and
+    the preview costs one extra reduce per round.  `to_reduce` moves a tensor to where the backend wants it (e.g.
+    `.cpu()` for gloo).  Returns the final mean on dst, None elsewhere.
+    """
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    step = preview_every if preview_every and preview_every > 0 else max(n_frames, 1)
+    done = 0
+    while done < n_frames:
+        chunk = min(step, n_frames - done)
+        first, count, stride = frames_for_rank(first_frame + done, chunk, rank, world)
+        if count:
+            render_frames(first, count, stride)
+        done += chunk
+        if done < n_frames and on_preview is not None:
+            snap = to_reduce(acc).clone()
+            if multi:
+                dist.reduce(snap, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            if rank == dst:
+                snap = snap * (1.0 / float(done))
+                snap[..., 3] = 1.0
+                on_preview(snap, done)
+    return reduce_accumulation(to_reduce(acc), n_frames, dst=dst, group=group)

@@ -74,3 +74,48 @@ def test_two_rank_sample_striding_matches_single_rank(tmp_path, ptlib, oracle):
     ref = o.render(s, oracle.ISECT_BRUTE, oracle.RNG_NODE, oracle.MATH_DET, 0, 6, want_ldr=False)["acc"]   # running mean
     assert (got[..., 3] == 1).all()
     assert np.allclose(got[..., :3], ref[..., :3], rtol=1e-5, atol=1e-6)      # summation order differs
+
+
+PROGRESSIVE_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+from cudapathtracer_amd.dist import render_progressive
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+acc = torch.zeros((4, 6, 4))
+rendered = []
+def render_frames(first, count, stride):          # stand-in for tracer.render(..., sum_mode=1): frame f adds f+1 everywhere
+    for i in range(count):
+        f = first + i * stride
+        rendered.append(f)
+        acc[..., :3] += float(f + 1)
+previews = []
+mean = render_progressive(render_frames, acc, 3, 11, rank, world, preview_every=4, on_preview=lambda img, n: previews.append((n, img.clone())))
+lists = [None] * world
+dist.all_gather_object(lists, rendered)
+if rank == 0:
+    frames = sorted(f for l in lists for f in l)
+    assert frames == list(range(3, 14)), frames                        # every frame exactly once across the ranks
+    assert [n for n, _ in previews] == [4, 8]                          # previews after 4 and 8 of 11 frames, none at the end
+    for n, img in previews:
+        assert torch.allclose(img[..., :3], torch.full((4, 6, 3), sum(range(4, 4 + n)) / n)) and (img[..., 3] == 1).all()
+    assert torch.allclose(mean[..., :3], torch.full((4, 6, 3), sum(range(4, 15)) / 11.0)) and (mean[..., 3] == 1).all()
+    open(os.environ["OUT"], "w").write("ok")
+else:
+    assert mean is None and previews == []
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_progressive_preview_reduce(tmp_path, world):
+    out = str(tmp_path / "ok.txt")
+    script = tmp_path / "worker.py"
+    script.write_text(PROGRESSIVE_WORKER)
+    env = dict(os.environ, REPO=ROOT, OUT=out, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(out).read() == "ok"
