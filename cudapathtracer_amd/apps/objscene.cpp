@@ -1,12 +1,13 @@
-// Headless OBJ viewer: a Wavefront OBJ mesh on the DefaultScene's ground quad under the synthetic sky (or a Radiance
+// Headless mesh viewer: a Wavefront OBJ (or Stanford PLY, by extension) mesh on the DefaultScene's ground quad under the synthetic sky (or a Radiance
 // .hdr file), rendered through the same RendererWindow call sequence as the two reference apps.  Not in the reference
 // (its scenes are procedural); it exercises the ingestion side of the path: ObjLoader.hpp, the parallel SBVH build and
 // the BVH cache ($MIPT_BVH_CACHE or the 7th argument).
-//   objscene mesh.obj [width height frames out.ppm [out.pfm [bvh.cache [sky.hdr]]]]
+//   objscene mesh.obj|mesh.ply [width height frames out.ppm [out.pfm [bvh.cache [sky.hdr]]]]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include "../cpp/ObjLoader.hpp"
+#include "../cpp/PlyLoader.hpp"
 #include "../cpp/RendererWindow.hpp"
 #include "../cpp/Rgbe.hpp"
 
@@ -20,7 +21,9 @@ int main(int argc, char** argv) {
         SurfaceMaterial groundMat{}; groundMat.color = { 0.9f, 0.9f, 0.8f }; groundMat.roughness = 0.5f; groundMat.metallic = 0.01f; groundMat.opacity = 1.f; groundMat.n = 2.7f;
         Scene scene{ { { 0.98f, 0.97f, 0.99f }, -Math::normalize(Math::vec3f{ 1, 1, 1 }), 5.f }, {}, {}, {} };
         auto t0 = std::chrono::steady_clock::now();
-        scene.objects.push_back(ConstructMesh(LoadOBJ(argv[1]), meshMat, Math::mat4x4f(1.f)));
+        const std::string meshPath = argv[1];
+        const bool ply = meshPath.size() > 4 && meshPath.compare(meshPath.size() - 4, 4, ".ply") == 0;
+        scene.objects.push_back(ConstructMesh(ply ? LoadPLY(meshPath) : LoadOBJ(meshPath), meshMat, Math::mat4x4f(1.f)));
         scene.objects.push_back(ConstructMesh(MakeQuad(), groundMat, Math::MatMul(Math::MakeTranslate(Math::vec3f{ -4, 0, -4 }), Math::MakeScale(Math::vec3f{ 8, 1, 8 }))));
         if (argc > 8) {
             int mw = 0, mh = 0;

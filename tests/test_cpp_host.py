@@ -270,3 +270,79 @@ def test_objscene_app_loads_builds_caches_and_renders(tmp_path):
     hdr = b"PF\n96 64\n-1.0\n"
     a, b = (np.frombuffer(o[len(hdr):], np.float32) for o in outs)
     assert np.allclose(a, b, rtol=1e-4, atol=1e-6) and a.mean() > 0.01      # same BVH -> same image (up to add order)
+
+
+PLY_MAIN = r"""
+#include <cstdio>
+#include "PlyLoader.hpp"
+using namespace CUDATracer;
+int main(int argc, char** argv) {
+    try {
+        auto m = LoadPLY(argv[1]);
+        auto& v = std::get<0>(m); auto& i = std::get<1>(m);
+        std::printf("%zu %zu\n", v.size(), i.size());
+        for (auto& x : v) std::printf("%g %g %g  %.6f %.6f %.6f  %g %g\n", x.position.x, x.position.y, x.position.z, x.normal.x, x.normal.y, x.normal.z, x.uv.x, x.uv.y);
+        for (size_t k = 0; k < i.size(); k += 3) std::printf("t %u %u %u\n", i[k], i[k + 1], i[k + 2]);
+    } catch (const std::exception& e) { std::printf("error: %s\n", e.what()); return 1; }
+    return 0;
+}
+"""
+
+
+def _ply_files(tmp_path):
+    """the same pyramid (square base as one quad, four sides) as ascii without normals and as little-endian binary with
+    normals, texture coordinates, an extra vertex property, an extra list property on the faces and a trailing element"""
+    import struct
+    pos = [(-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), (0, 1.5, 0)]
+    faces = [(0, 1, 2, 3), (0, 4, 1), (1, 4, 2), (2, 4, 3), (3, 4, 0)]
+    a = tmp_path / "pyr_ascii.ply"
+    a.write_text("ply\nformat ascii 1.0\ncomment made by the test\nelement vertex 5\nproperty float x\nproperty float y\nproperty float z\n"
+                 "element face 5\nproperty list uchar int vertex_indices\nend_header\n" +
+                 "".join(f"{x} {y} {z}\n" for x, y, z in pos) + "".join(f"{len(f)} " + " ".join(map(str, f)) + "\n" for f in faces))
+    b = tmp_path / "pyr_bin.ply"
+    hdr = ("ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty double x\nproperty double y\nproperty double z\n"
+           "property uchar red\nproperty float nx\nproperty float ny\nproperty float nz\nproperty float s\nproperty float t\n"
+           "element face 5\nproperty list uchar ushort vertex_index\nproperty list uchar float texcoord\n"
+           "element edge 1\nproperty int vertex1\nproperty int vertex2\nend_header\n").encode()
+    body = b""
+    for k, (x, y, z) in enumerate(pos):
+        body += struct.pack("<dddBfffff", x, y, z, 200, 0.0, 1.0, 0.0, 0.25 * k, 0.5)
+    for f in faces:
+        body += struct.pack("<B" + "H" * len(f), len(f), *f) + struct.pack("<Bff", 2, 0.1, 0.2)
+    body += struct.pack("<ii", 0, 1)
+    b.write_bytes(hdr + body)
+    return a, b
+
+
+def test_ply_loader_ascii_and_binary(tmp_path):
+    src = tmp_path / "ply_main.cpp"
+    src.write_text(PLY_MAIN)
+    exe = str(tmp_path / "ply_main")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "cudapathtracer_amd", "cpp"), str(src), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = _ply_files(tmp_path)
+    outs = []
+    for f in (a, b):
+        r = subprocess.run([exe, str(f)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout
+        lines = r.stdout.strip().splitlines()
+        assert lines[0] == "5 18"                                     # 1 quad -> 2 triangles, + 4 sides
+        verts = np.array([[float(x) for x in l.split()] for l in lines[1:6]])
+        tris = np.array([[int(x) for x in l.split()[1:]] for l in lines[6:]])
+        outs.append((verts, tris))
+    (va, ta), (vb, tb) = outs
+    assert np.array_equal(ta, tb) and np.array_equal(ta[:2], [(0, 1, 2), (0, 2, 3)]) and np.allclose(va[:, :3], vb[:, :3])
+    # ascii file: smooth normals, unit length; the apex normal is the (area-weighted) mean of four symmetric sides: +y
+    assert np.allclose(np.linalg.norm(va[:, 3:6], axis=1), 1, atol=1e-5) and np.allclose(va[4, 3:6], (0, 1, 0), atol=1e-6)
+    # binary file: normals and s/t come from the file, unrelated properties are skipped
+    assert np.allclose(vb[:, 3:6], (0, 1, 0)) and np.allclose(vb[:, 6], 0.25 * np.arange(5)) and np.allclose(vb[:, 7], 0.5)
+    # malformed inputs
+    bad = tmp_path / "bad.ply"
+    for text, msg in (("plx\n", "magic"), ("ply\nformat binary_big_endian 1.0\nend_header\n", "unsupported format"),
+                      ("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nend_header\n0\n", "without x y z"),
+                      ("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nelement face 1\n"
+                       "property list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 3\n", "out of range"),
+                      ("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nend_header\n0 0 0\n1 0\n", "end of data")):
+        bad.write_text(text)
+        r = subprocess.run([exe, str(bad)], capture_output=True, text=True)
+        assert r.returncode == 1 and msg in r.stdout, (text, r.stdout)
