@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--integrator", type=int, default=0, help="0 persistent wave stacks (default), 1 level-synchronous queues")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (default); gloo = rehearsal of the N>1 flow through host memory")
     p.add_argument("--node-width", type=int, default=0, help="BVH node layout: 0 library default, 2 fp32 BVH2, 4 quantised 4-wide")
+    p.add_argument("--pipeline", type=int, default=1, help="1 (default): consecutive frames alternate between two streams so a frame's tail overlaps the next frame; 0: one stream")
     p.add_argument("--estimator", type=int, default=0, help="0 the reference's estimator (default, the parity configuration); 1 env-map / emitter sampling with occlusion rays")
     p.add_argument("--traffic-gb", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC run (GB)")
     return p.parse_args()
@@ -131,6 +132,7 @@ def main():
         t.set_option("tile_pixels", a.tile_pixels)
     t.set_option("integrator", a.integrator)
     t.set_option("estimator", a.estimator)
+    t.set_option("pipeline_frames", a.pipeline)
     sc = pt.Scene(t, data, node_width=a.node_width)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     ldr = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
@@ -224,6 +226,12 @@ def main():
                     "kernel": kernel_name, "bytes_per_ray": round(b_ray, 1), "n_node_per_ray": round(n_node, 3),
                     "n_tri_per_ray": round(n_tri, 3), "rays_per_launch": round(sec_rays / max(sec_launches, 1), 1),
                     "avg_launch_ms": round(sec_ms / max(sec_launches, 1), 4), "launches": int(sec_launches),
+                    # consecutive frames run on two streams, so a launch's event window includes the time it shares the GPU
+                    # with (or queues behind) its neighbour; the wall figures divide the timed region by the launches instead
+                    "frames_pipelined": bool(a.pipeline and a.integrator == 0),
+                    "wall_ms_per_launch": round(dt * 1e3 / a.steps, 4),
+                    "achieved_wall": round(sec_rays / max(sec_launches, 1) * b_ray / (dt / a.steps) / 1e9, 1),
+                    "frac_wall": round(sec_rays / max(sec_launches, 1) * b_ray / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 4),
                     "working_set_mb": round((nn * 64 + nr * 48) / 1e6, 2),
                     # issue-side PMC figures of the same command (profiles/r1, scripts/pmc_to_json.py): what binds when HBM does not
                     "pmc": pmc or None,

@@ -36,6 +36,7 @@ struct mipt_tracer {
     int64_t estimator = 0;
     int64_t profileLevels = 0;
     int64_t integrator = 0;          // 0 persistent wave stacks, 1 level-synchronous queues
+    int64_t pipelineFrames = 1;      // consecutive frames alternate between two streams / buffer sets (see mipt_render)
     // work buffers
     Queue wstack = {}; size_t wstackEntries = 0;
     Queue q[2] = {};
@@ -44,6 +45,18 @@ struct mipt_tracer {
     unsigned long long* stats = nullptr;      // [0] rays
     float* sample = nullptr; size_t samplePixels = 0;
     uint32_t* pixelRays = nullptr; size_t pixelRaysCap = 0;
+    // second buffer set + stream of the frame pipeline (set 1; the members above are set 0 on `stream`)
+    hipStream_t aux = nullptr;
+    Queue wstack2 = {}; size_t wstack2Entries = 0;
+    float* sample2 = nullptr; size_t sample2Pixels = 0;
+    uint32_t* counts2 = nullptr;
+    hipEvent_t accEv[2] = { nullptr, nullptr };   // "accumulate of the last frame on set s is enqueued up to here"
+    hipEvent_t joinEv = nullptr;
+    bool accValid[2] = { false, false };
+    bool auxBusy = false;            // work was enqueued on `aux` that `stream` has not been ordered after yet
+    bool mainTouched = true;         // something other than a pipelined frame was enqueued on `stream` since aux last waited on it
+    uint32_t flip = 0;               // next frame's buffer set
+    int lastSet = 0;                 // buffer set of the most recent frame (mipt_last_sample)
     // counters
     uint64_t frames = 0, launches = 0; double kernelMs = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -76,7 +89,19 @@ int fail(mipt_tracer* t, int code, const std::string& msg) { if (t) t->err = msg
 #define HIPCHK(t, call)                                                                                   \
     do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((t), MIPT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
-int use(mipt_tracer* t) { hipError_t e = hipSetDevice(t->device); if (e != hipSuccess) return fail(t, MIPT_E_HIP, "hipSetDevice failed"); return MIPT_OK; }
+int use_device(mipt_tracer* t) { hipError_t e = hipSetDevice(t->device); if (e != hipSuccess) return fail(t, MIPT_E_HIP, "hipSetDevice failed"); return MIPT_OK; }
+// Orders `stream` after everything the frame pipeline has put on `aux`, so that whatever the caller does next on the
+// tracer's stream (read-back, tonemap, synchronize ...) sees every frame rendered so far.
+void join_aux(mipt_tracer* t) {
+    if (t->auxBusy && t->aux && t->joinEv) {
+        hipEventRecord(t->joinEv, t->aux);
+        hipStreamWaitEvent(t->stream, t->joinEv, 0);
+        t->auxBusy = false;
+    }
+    t->mainTouched = true;
+}
+// every entry point except the frame pipeline itself
+int use(mipt_tracer* t) { int rc = use_device(t); if (rc) return rc; join_aux(t); return MIPT_OK; }
 
 void free_queue(Queue& q) { if (q.a) hipFree(q.a); if (q.b) hipFree(q.b); if (q.c) hipFree(q.c); q = Queue{}; }
 
@@ -249,6 +274,10 @@ int mipt_create(int device, mipt_tracer** out) {
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) t->numCU = cu;
     if (hipStreamCreateWithFlags(&t->own, hipStreamNonBlocking) != hipSuccess) { delete t; return MIPT_E_HIP; }
     t->stream = t->own;
+    if (hipStreamCreateWithFlags(&t->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->joinEv, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&t->accEv[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t->accEv[1], hipEventDisableTiming) != hipSuccess) {
+        mipt_destroy(t); return MIPT_E_HIP;
+    }
     if (hipMalloc((void**)&t->counts, 64 * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&t->stats, 40 * sizeof(unsigned long long)) != hipSuccess) {
         mipt_destroy(t); return MIPT_E_NOMEM;
     }
@@ -262,8 +291,13 @@ void mipt_destroy(mipt_tracer* t) {
     if (!t) return;
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
+    if (t->aux) hipStreamSynchronize(t->aux);
     resolve_events(t);
-    free_queue(t->q[0]); free_queue(t->q[1]); free_queue(t->wstack);
+    free_queue(t->q[0]); free_queue(t->q[1]); free_queue(t->wstack); free_queue(t->wstack2);
+    if (t->sample2) hipFree(t->sample2);
+    if (t->counts2) hipFree(t->counts2);
+    for (hipEvent_t e : { t->accEv[0], t->accEv[1], t->joinEv }) if (e) hipEventDestroy(e);
+    if (t->aux) hipStreamDestroy(t->aux);
     if (t->counts) hipFree(t->counts);
     if (t->stats) hipFree(t->stats);
     if (t->sample) hipFree(t->sample);
@@ -274,7 +308,14 @@ void mipt_destroy(mipt_tracer* t) {
 
 const char* mipt_last_error(const mipt_tracer* t) { return t ? t->err.c_str() : "null tracer"; }
 
-int mipt_set_stream(mipt_tracer* t, void* s) { if (!t) return MIPT_E_INVALID; t->stream = s ? (hipStream_t)s : t->own; return MIPT_OK; }
+int mipt_set_stream(mipt_tracer* t, void* s) {
+    if (!t) return MIPT_E_INVALID;
+    if (use(t)) return MIPT_E_HIP;                   // the old stream is ordered after the pipeline's aux stream first
+    hipStream_t ns = s ? (hipStream_t)s : t->own;
+    if (ns != t->stream) { hipStreamSynchronize(t->stream); t->accValid[0] = t->accValid[1] = false; }
+    t->stream = ns;
+    return MIPT_OK;
+}
 
 int mipt_synchronize(mipt_tracer* t) {
     if (!t) return MIPT_E_INVALID;
@@ -299,6 +340,7 @@ int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
     else if (k == "count_pixel_rays") t->countPixelRays = v ? 1 : 0;
     else if (k == "refill_lanes") { if (v < 1 || v > 64) return fail(t, MIPT_E_INVALID, "refill_lanes out of range"); t->refillLanes = v; }
     else if (k == "min_descend_lanes") { if (v < 0 || v > 64) return fail(t, MIPT_E_INVALID, "min_descend_lanes out of range"); t->minDescend = v; }
+    else if (k == "pipeline_frames") t->pipelineFrames = v ? 1 : 0;
     else if (k == "estimator") { if (v != 0 && v != 1) return fail(t, MIPT_E_INVALID, "estimator must be 0 (reference) or 1 (env-map importance sampling)"); t->estimator = v; }
     else if (k == "profile_levels") t->profileLevels = v ? 1 : 0;
     else if (k == "integrator") { if (v != 0 && v != 1) return fail(t, MIPT_E_INVALID, "integrator must be 0 (wave stacks) or 1 (level queues)"); t->integrator = v; }
@@ -489,7 +531,7 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
                 uint32_t frame_stride, int sum_mode, float* acc_dev, unsigned char* ldr_dev) {
     if (!t || !sc || !st || !acc_dev) return fail(t, MIPT_E_INVALID, "null argument");
     if (sc->t != t) return fail(t, MIPT_E_INVALID, "scene belongs to another tracer");
-    if (use(t)) return MIPT_E_HIP;
+    if (use_device(t)) return MIPT_E_HIP;
     const uint32_t W = st->viewportWidth, H = st->viewportHeight, D = st->maxDepth;
     if (!W || !H) return fail(t, MIPT_E_INVALID, "empty viewport");
     if ((uint64_t)W * H >= (1ull << 31)) return fail(t, MIPT_E_LIMIT, "viewport too large");
@@ -518,6 +560,15 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
     const int persistentBlocks = t->numCU * (int)t->blocksPerCU;
     uint32_t tile = npix;
     uint32_t wcap = 0;
+    // Frame pipeline.  A wave of the persistent kernel cannot give work away, so a frame ends with a tail in which the
+    // waves holding the heaviest pixels finish alone (measured: 10-20 % of a 1080p frame, scripts/tail_profile.py).
+    // Consecutive frames therefore alternate between two streams with their own sample buffer, wave stacks and pixel
+    // counter: the next frame's blocks move onto the CUs as the previous frame's blocks retire.  Only the accumulation
+    // into the caller's buffers is chained frame by frame (events), so the running mean is folded in frame order.
+    // Off for a caller-supplied stream (the caller expects everything in order there), per-pixel ray counting, and
+    // the other integrators.
+    const bool pipe = t->pipelineFrames && t->stream == t->own && !t->countPixelRays && t->rngMode == MIPT_RNG_NODE && t->integrator == 0 && D >= 1;
+    if (!pipe) join_aux(t);
     if (t->rngMode == MIPT_RNG_DFS) {
         // depth-first integrator: no queues
     } else if (t->integrator == 0) {
@@ -530,6 +581,22 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
             HIPCHK(t, hipMalloc((void**)&t->wstack.b, need * sizeof(float4)));
             HIPCHK(t, hipMalloc((void**)&t->wstack.c, need * sizeof(float4)));
             t->wstackEntries = need;
+        }
+        if (pipe) {
+            if (t->wstack2Entries < need) {
+                free_queue(t->wstack2); t->wstack2Entries = 0;
+                HIPCHK(t, hipMalloc((void**)&t->wstack2.a, need * sizeof(float4)));
+                HIPCHK(t, hipMalloc((void**)&t->wstack2.b, need * sizeof(float4)));
+                HIPCHK(t, hipMalloc((void**)&t->wstack2.c, need * sizeof(float4)));
+                t->wstack2Entries = need;
+            }
+            if (t->sample2Pixels < npix) {
+                if (t->sample2) hipFree(t->sample2);
+                t->sample2 = nullptr; t->sample2Pixels = 0;
+                HIPCHK(t, hipMalloc((void**)&t->sample2, (size_t)npix * 16));
+                t->sample2Pixels = npix;
+            }
+            if (!t->counts2) HIPCHK(t, hipMalloc((void**)&t->counts2, 64 * sizeof(uint32_t)));
         }
     } else if (D >= 2) {
     // tile size: rays at level k <= tile * 2^k; the two ping-pong queues hold the largest odd / even level
@@ -547,64 +614,83 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
         if (evenMax >= 2) { rc = ensure_queue(t, 0, (size_t)tile << evenMax); if (rc) return rc; }
     }
 
-    hipEvent_t ev0, ev1;
-    HIPCHK(t, hipEventCreate(&ev0)); HIPCHK(t, hipEventCreate(&ev1));
-    HIPCHK(t, hipEventRecord(ev0, t->stream));
+    if (pipe && t->mainTouched) {       // aux starts after whatever else the caller queued on the tracer's stream (clears, uploads ...)
+        HIPCHK(t, hipEventRecord(t->joinEv, t->stream));
+        HIPCHK(t, hipStreamWaitEvent(t->aux, t->joinEv, 0));
+        t->mainTouched = false;
+    }
     for (uint32_t fi = 0; fi < n_frames; fi++) {
         const uint32_t frame = first_frame + fi * frame_stride;
-        HIPCHK(t, hipMemsetAsync(t->sample, 0, (size_t)npix * 16, t->stream));
-        if (t->countPixelRays) HIPCHK(t, hipMemsetAsync(t->pixelRays, 0, (size_t)npix * 4, t->stream));
+        const int set = pipe ? (int)(t->flip++ & 1u) : 0;
+        hipStream_t S = set ? t->aux : t->stream;
+        float* sample = set ? t->sample2 : t->sample;
+        uint32_t* counts = set ? t->counts2 : t->counts;
+        if (set) t->auxBusy = true;
+        t->lastSet = set;
+        HIPCHK(t, hipMemsetAsync(sample, 0, (size_t)npix * 16, S));
+        if (t->countPixelRays) HIPCHK(t, hipMemsetAsync(t->pixelRays, 0, (size_t)npix * 4, S));
         LevelArgs A;
         A.S = sc->dev; A.F = make_frame(*st, frame);
-        A.sample = t->sample; A.pixelRays = t->countPixelRays ? t->pixelRays : nullptr; A.stats = t->stats;
+        A.sample = sample; A.pixelRays = t->countPixelRays ? t->pixelRays : nullptr; A.stats = t->stats;
+        hipEvent_t ka, kb;                  // integrator kernel time of this frame (they overlap across frames when pipelined)
+        HIPCHK(t, hipEventCreate(&ka)); HIPCHK(t, hipEventCreate(&kb));
         if (t->rngMode == MIPT_RNG_DFS) {
             DfsArgs DA;
             DA.S = sc->dev; DA.F = A.F; DA.sample = A.sample; DA.pixelRays = A.pixelRays; DA.stats = t->stats; DA.pix0 = 0; DA.npix = npix;
             mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
-            if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, t->stream)); }
-            launch_dfs(DA, 0, t->stream);
-            if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, t->stream)); t->levelPending.push_back(le); }
+            if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, S)); }
+            HIPCHK(t, hipEventRecord(ka, S));
+            launch_dfs(DA, 0, S);
+            HIPCHK(t, hipEventRecord(kb, S));
+            if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, S)); t->levelPending.push_back(le); }
             t->launches++;
         } else if (t->integrator == 0 && D >= 1) {
-            HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), t->stream));
+            HIPCHK(t, hipMemsetAsync(counts, 0, 64 * sizeof(uint32_t), S));
             StackArgs SA;
-            SA.S = sc->dev; SA.F = A.F; SA.stack = t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes;
+            SA.S = sc->dev; SA.F = A.F; SA.stack = set ? t->wstack2 : t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes;
             // min_descend_lanes auto: 8 for an LDS-resident scene, 24 otherwise (measured optima, profiles/r1/exp_min_descend.log)
             const bool ldsScene = !sc->dev.wide && sc->dev.nNodes * 4 + sc->dev.nRefs * 3 <= 256;
             SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (ldsScene ? 8 : 24));
-            SA.pixCounter = t->counts; SA.nee = nee ? 1u : 0u;
+            SA.pixCounter = counts; SA.nee = nee ? 1u : 0u;
             SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npix;
             mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
-            if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, t->stream)); }
-            launch_wavestack(SA, std::min<int>((int)((npix + 255) / 256), persistentBlocks), t->stream);
-            if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, t->stream)); t->levelPending.push_back(le); }
+            if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, S)); }
+            HIPCHK(t, hipEventRecord(ka, S));
+            launch_wavestack(SA, std::min<int>((int)((npix + 255) / 256), persistentBlocks), S);
+            HIPCHK(t, hipEventRecord(kb, S));
+            if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, S)); t->levelPending.push_back(le); }
             t->launches++;
-        } else
-        for (uint32_t p0 = 0; p0 < npix; p0 += tile) {
-            const uint32_t np = std::min(tile, npix - p0);
-            HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), t->stream));
-            A.pix0 = p0; A.npix = np;
-            for (uint32_t k = 0; k < D; k++) {
-                A.level = k;
-                A.qin = t->q[k & 1]; A.qout = t->q[(k + 1) & 1];
-                A.inCount = t->counts + k; A.outCount = t->counts + k + 1;
-                int blocks = k == 0 ? std::min<int>((int)((np + 255) / 256), persistentBlocks) : persistentBlocks;
-                mipt_tracer::LevelEv le{ nullptr, nullptr, (int)k };
-                if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, t->stream)); }
-                launch_level(A, k == 0, blocks, t->stream);
-                if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, t->stream)); t->levelPending.push_back(le); }
-                t->launches++;
+        } else {
+            HIPCHK(t, hipEventRecord(ka, S));
+            for (uint32_t p0 = 0; p0 < npix; p0 += tile) {
+                const uint32_t np = std::min(tile, npix - p0);
+                HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), S));
+                A.pix0 = p0; A.npix = np;
+                for (uint32_t k = 0; k < D; k++) {
+                    A.level = k;
+                    A.qin = t->q[k & 1]; A.qout = t->q[(k + 1) & 1];
+                    A.inCount = t->counts + k; A.outCount = t->counts + k + 1;
+                    int blocks = k == 0 ? std::min<int>((int)((np + 255) / 256), persistentBlocks) : persistentBlocks;
+                    mipt_tracer::LevelEv le{ nullptr, nullptr, (int)k };
+                    if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, S)); }
+                    launch_level(A, k == 0, blocks, S);
+                    if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, S)); t->levelPending.push_back(le); }
+                    t->launches++;
+                }
             }
+            HIPCHK(t, hipEventRecord(kb, S));
         }
+        t->pending.emplace_back(ka, kb);
+        // fold into the caller's buffers in frame order: after the previous frame's fold, which may sit on the other stream
+        if (pipe && t->accValid[1 - set]) HIPCHK(t, hipStreamWaitEvent(S, t->accEv[1 - set], 0));
         const float weight = (float)(1.0 / (frame + 1.0));       // CUDATracerProg.cu:878
         mipt_tracer::LevelEv ae{ nullptr, nullptr, -1 };
-        if (t->profileLevels) { HIPCHK(t, hipEventCreate(&ae.a)); HIPCHK(t, hipEventCreate(&ae.b)); HIPCHK(t, hipEventRecord(ae.a, t->stream)); }
-        launch_accumulate(t->sample, acc_dev, ldr_dev, weight, sum_mode, 0, npix, t->stream);
-        if (t->profileLevels) { HIPCHK(t, hipEventRecord(ae.b, t->stream)); t->levelPending.push_back(ae); }
+        if (t->profileLevels) { HIPCHK(t, hipEventCreate(&ae.a)); HIPCHK(t, hipEventCreate(&ae.b)); HIPCHK(t, hipEventRecord(ae.a, S)); }
+        launch_accumulate(sample, acc_dev, ldr_dev, weight, sum_mode, 0, npix, S);
+        if (t->profileLevels) { HIPCHK(t, hipEventRecord(ae.b, S)); t->levelPending.push_back(ae); }
+        HIPCHK(t, hipEventRecord(t->accEv[set], S)); t->accValid[set] = true;
         t->frames++;
     }
-    HIPCHK(t, hipEventRecord(ev1, t->stream));
-    t->pending.emplace_back(ev0, ev1);
     HIPCHK(t, hipGetLastError());
     if (t->pending.size() > 256 || t->levelPending.size() > 4096) resolve_events(t);
     return MIPT_OK;
@@ -626,11 +712,11 @@ int mipt_tonemap(mipt_tracer* t, const float* acc_dev, float scale, uint32_t n_p
 int mipt_last_sample(mipt_tracer* t, float* rgb_host, uint32_t* rays_host, uint32_t n_pixels) {
     if (!t) return MIPT_E_INVALID;
     if (use(t)) return MIPT_E_HIP;
-    if (n_pixels > t->samplePixels) return fail(t, MIPT_E_INVALID, "no sample of that size");
+    if (n_pixels > (t->lastSet ? t->sample2Pixels : t->samplePixels)) return fail(t, MIPT_E_INVALID, "no sample of that size");
     HIPCHK(t, hipStreamSynchronize(t->stream));
     if (rgb_host) {
         std::vector<float> tmp((size_t)n_pixels * 4);
-        HIPCHK(t, hipMemcpy(tmp.data(), t->sample, tmp.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(t, hipMemcpy(tmp.data(), t->lastSet ? t->sample2 : t->sample, tmp.size() * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n_pixels; i++) { rgb_host[i * 3] = tmp[i * 4]; rgb_host[i * 3 + 1] = tmp[i * 4 + 1]; rgb_host[i * 3 + 2] = tmp[i * 4 + 2]; }
     }
     if (rays_host) {
@@ -665,7 +751,7 @@ void mipt_buffer_destroy(mipt_buffer* b) {
     delete b;
 }
 static bool buf_to_cpu(mipt_buffer* b) {
-    hipSetDevice(b->t->device);
+    if (use(b->t)) return false;
     size_t sz = b->size ? b->size : 1;
     switch (b->head) {
         case MIPT_HEAD_UNINITIALIZED:
@@ -682,7 +768,7 @@ static bool buf_to_cpu(mipt_buffer* b) {
     return true;
 }
 static bool buf_to_gpu(mipt_buffer* b) {
-    hipSetDevice(b->t->device);
+    if (use(b->t)) return false;
     size_t sz = b->size ? b->size : 1;
     switch (b->head) {
         case MIPT_HEAD_UNINITIALIZED:

@@ -433,3 +433,47 @@ def test_large_scene_parallel_build_q4_and_cache_on_gpu(tracer, ptlib, oracle, t
     assert (c["tri"] >= 0).mean() > 0.5
     for sc in (built, loaded):
         assert hits_equal(tracer.trace_rays(sc, og, dg), c) == 0
+
+
+def test_frame_pipeline_equals_serial_frames(tracer, ptlib):
+    """Consecutive frames alternate between two streams / buffer sets (mipt_render's frame pipeline); the running mean
+    must come out as with one stream, whatever else the caller queues in between (clears, read-backs, tonemap, a
+    single-frame Trace loop, sum mode)."""
+    data = ptlib.builtin_scene(1, ptlib.synthetic_sky(64, 32))
+    sc = ptlib.Scene(tracer, data)
+    w, h = 200, 120
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.DEFAULT_CAMERA), w, h, 6)
+
+    def run(pipeline):
+        tracer.set_option("pipeline_frames", pipeline)
+        acc, ldr = dev_buffers(tracer, w, h)
+        tracer.render(sc, s, 0, 7, acc, ldr)                         # one batch of 7 frames
+        a7 = tracer.download(acc, (h, w, 4), np.float32)            # read-back in the middle
+        for f in range(7, 12):                                       # Trace loop, one frame per call, no sync in between
+            s.frameID = f
+            tracer.trace(sc, s, acc, ldr)
+        a12 = tracer.download(acc, (h, w, 4), np.float32)
+        l12 = tracer.download(ldr, (h, w, 4), np.uint8)
+        tracer.memset(acc, 0, w * h * 16)                            # a clear on the tracer's stream, then sum mode with a stride
+        tracer.render(sc, s, 1, 5, acc, None, 2, 1)
+        tm = tracer.malloc(w * h * 4)
+        tracer.tonemap(acc, 1.0 / 5, w * h, tm)
+        asum = tracer.download(acc, (h, w, 4), np.float32)
+        ltm = tracer.download(tm, (h, w, 4), np.uint8)
+        c = tracer.counters()
+        tracer.free(acc), tracer.free(ldr), tracer.free(tm)
+        return a7, a12, l12, asum, ltm, c.rays, c.frames
+
+    tracer.reset_counters()
+    try:
+        ser = run(0)
+        tracer.reset_counters()
+        pip = run(1)
+    finally:
+        tracer.set_option("pipeline_frames", 1)
+        s.frameID = 0
+    for k in (0, 1, 3):
+        assert rel_err(pip[k], ser[k]).max() < RTOL * 4, k
+    for k in (2, 4):
+        assert np.abs(pip[k].astype(int) - ser[k].astype(int)).max() <= 1
+    assert pip[5] == ser[5] and pip[6] == ser[6] == 17                 # same rays, same frame count
