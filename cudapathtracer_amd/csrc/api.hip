@@ -45,18 +45,20 @@ struct mipt_tracer {
     unsigned long long* stats = nullptr;      // [0] rays
     float* sample = nullptr; size_t samplePixels = 0;
     uint32_t* pixelRays = nullptr; size_t pixelRaysCap = 0;
-    // second buffer set + stream of the frame pipeline (set 1; the members above are set 0 on `stream`)
-    hipStream_t aux = nullptr;
+    // frame pipeline (mipt_render): set 1 of the integrator's buffers on `aux` (set 0 = the members above on `stream`),
+    // a ring of sample buffers, and a high-priority stream for the folds into the caller's buffers
+    hipStream_t aux = nullptr, fold = nullptr;
     Queue wstack2 = {}; size_t wstack2Entries = 0;
-    float* sample2 = nullptr; size_t sample2Pixels = 0;
     uint32_t* counts2 = nullptr;
-    hipEvent_t accEv[2] = { nullptr, nullptr };   // "accumulate of the last frame on set s is enqueued up to here"
+    static constexpr int kRing = 4;
+    float* ring[kRing] = {}; size_t ringPixels = 0;          // ring[0] aliases `sample`
+    hipEvent_t kernEv[kRing] = {}, foldEv[kRing] = {};       // integrator of / fold of the frame that last used the slot
+    bool foldValid[kRing] = {};
     hipEvent_t joinEv = nullptr;
-    bool accValid[2] = { false, false };
-    bool auxBusy = false;            // work was enqueued on `aux` that `stream` has not been ordered after yet
-    bool mainTouched = true;         // something other than a pipelined frame was enqueued on `stream` since aux last waited on it
-    uint32_t flip = 0;               // next frame's buffer set
-    int lastSet = 0;                 // buffer set of the most recent frame (mipt_last_sample)
+    bool pipeBusy = false;           // frames are in flight that `stream` has not been ordered after yet
+    bool mainTouched = true;         // something other than a pipelined frame was enqueued on `stream` since aux/fold last waited on it
+    uint32_t flip = 0;               // frames rendered through the pipeline
+    int lastSlot = 0;                // ring slot of the most recent frame (mipt_last_sample)
     // counters
     uint64_t frames = 0, launches = 0; double kernelMs = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -93,10 +95,10 @@ int use_device(mipt_tracer* t) { hipError_t e = hipSetDevice(t->device); if (e !
 // Orders `stream` after everything the frame pipeline has put on `aux`, so that whatever the caller does next on the
 // tracer's stream (read-back, tonemap, synchronize ...) sees every frame rendered so far.
 void join_aux(mipt_tracer* t) {
-    if (t->auxBusy && t->aux && t->joinEv) {
-        hipEventRecord(t->joinEv, t->aux);
+    if (t->pipeBusy && t->fold && t->joinEv) {       // every pipelined frame ends with its fold on `fold`, in frame order
+        hipEventRecord(t->joinEv, t->fold);
         hipStreamWaitEvent(t->stream, t->joinEv, 0);
-        t->auxBusy = false;
+        t->pipeBusy = false;
     }
     t->mainTouched = true;
 }
@@ -274,8 +276,14 @@ int mipt_create(int device, mipt_tracer** out) {
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) t->numCU = cu;
     if (hipStreamCreateWithFlags(&t->own, hipStreamNonBlocking) != hipSuccess) { delete t; return MIPT_E_HIP; }
     t->stream = t->own;
-    if (hipStreamCreateWithFlags(&t->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->joinEv, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&t->accEv[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&t->accEv[1], hipEventDisableTiming) != hipSuccess) {
+    int prLow = 0, prHigh = 0;
+    hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
+    bool ok = hipStreamCreateWithFlags(&t->aux, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithPriority(&t->fold, hipStreamNonBlocking, prHigh) == hipSuccess &&
+              hipEventCreateWithFlags(&t->joinEv, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < mipt_tracer::kRing && ok; i++)
+        ok = hipEventCreateWithFlags(&t->kernEv[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&t->foldEv[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
         mipt_destroy(t); return MIPT_E_HIP;
     }
     if (hipMalloc((void**)&t->counts, 64 * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&t->stats, 40 * sizeof(unsigned long long)) != hipSuccess) {
@@ -292,11 +300,14 @@ void mipt_destroy(mipt_tracer* t) {
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
     if (t->aux) hipStreamSynchronize(t->aux);
+    if (t->fold) hipStreamSynchronize(t->fold);
     resolve_events(t);
     free_queue(t->q[0]); free_queue(t->q[1]); free_queue(t->wstack); free_queue(t->wstack2);
-    if (t->sample2) hipFree(t->sample2);
+    for (int i = 1; i < mipt_tracer::kRing; i++) if (t->ring[i]) hipFree(t->ring[i]);
     if (t->counts2) hipFree(t->counts2);
-    for (hipEvent_t e : { t->accEv[0], t->accEv[1], t->joinEv }) if (e) hipEventDestroy(e);
+    for (int i = 0; i < mipt_tracer::kRing; i++) { if (t->kernEv[i]) hipEventDestroy(t->kernEv[i]); if (t->foldEv[i]) hipEventDestroy(t->foldEv[i]); }
+    if (t->joinEv) hipEventDestroy(t->joinEv);
+    if (t->fold) hipStreamDestroy(t->fold);
     if (t->aux) hipStreamDestroy(t->aux);
     if (t->counts) hipFree(t->counts);
     if (t->stats) hipFree(t->stats);
@@ -312,7 +323,7 @@ int mipt_set_stream(mipt_tracer* t, void* s) {
     if (!t) return MIPT_E_INVALID;
     if (use(t)) return MIPT_E_HIP;                   // the old stream is ordered after the pipeline's aux stream first
     hipStream_t ns = s ? (hipStream_t)s : t->own;
-    if (ns != t->stream) { hipStreamSynchronize(t->stream); t->accValid[0] = t->accValid[1] = false; }
+    if (ns != t->stream) hipStreamSynchronize(t->stream);
     t->stream = ns;
     return MIPT_OK;
 }
@@ -562,9 +573,11 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
     uint32_t wcap = 0;
     // Frame pipeline.  A wave of the persistent kernel cannot give work away, so a frame ends with a tail in which the
     // waves holding the heaviest pixels finish alone (measured: 10-20 % of a 1080p frame, scripts/tail_profile.py).
-    // Consecutive frames therefore alternate between two streams with their own sample buffer, wave stacks and pixel
-    // counter: the next frame's blocks move onto the CUs as the previous frame's blocks retire.  Only the accumulation
-    // into the caller's buffers is chained frame by frame (events), so the running mean is folded in frame order.
+    // Consecutive frames therefore alternate between two streams with their own wave stacks and pixel counter, writing
+    // into a ring of sample buffers: the next frame's blocks move onto the CUs as the previous frame's blocks retire.
+    // The folds into the caller's buffers go, in frame order, onto a third, high-priority stream (behind a persistent
+    // kernel's resident waves a normal-priority fold starves for milliseconds), so the running mean is folded in order
+    // and no integrator launch ever queues behind a fold.
     // Off for a caller-supplied stream (the caller expects everything in order there), per-pixel ray counting, and
     // the other integrators.
     const bool pipe = t->pipelineFrames && t->stream == t->own && !t->countPixelRays && t->rngMode == MIPT_RNG_NODE && t->integrator == 0 && D >= 1;
@@ -590,11 +603,14 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
                 HIPCHK(t, hipMalloc((void**)&t->wstack2.c, need * sizeof(float4)));
                 t->wstack2Entries = need;
             }
-            if (t->sample2Pixels < npix) {
-                if (t->sample2) hipFree(t->sample2);
-                t->sample2 = nullptr; t->sample2Pixels = 0;
-                HIPCHK(t, hipMalloc((void**)&t->sample2, (size_t)npix * 16));
-                t->sample2Pixels = npix;
+            if (t->ringPixels < npix) {
+                for (int i = 1; i < mipt_tracer::kRing; i++) {
+                    if (t->ring[i]) hipFree(t->ring[i]);
+                    t->ring[i] = nullptr;
+                }
+                t->ringPixels = 0;
+                for (int i = 1; i < mipt_tracer::kRing; i++) HIPCHK(t, hipMalloc((void**)&t->ring[i], (size_t)npix * 16));
+                t->ringPixels = npix;
             }
             if (!t->counts2) HIPCHK(t, hipMalloc((void**)&t->counts2, 64 * sizeof(uint32_t)));
         }
@@ -614,19 +630,24 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
         if (evenMax >= 2) { rc = ensure_queue(t, 0, (size_t)tile << evenMax); if (rc) return rc; }
     }
 
-    if (pipe && t->mainTouched) {       // aux starts after whatever else the caller queued on the tracer's stream (clears, uploads ...)
+    if (pipe && t->mainTouched) {       // aux / fold start after whatever else the caller queued on the tracer's stream (clears, uploads ...)
         HIPCHK(t, hipEventRecord(t->joinEv, t->stream));
         HIPCHK(t, hipStreamWaitEvent(t->aux, t->joinEv, 0));
+        HIPCHK(t, hipStreamWaitEvent(t->fold, t->joinEv, 0));
         t->mainTouched = false;
     }
+    t->ring[0] = t->sample;
     for (uint32_t fi = 0; fi < n_frames; fi++) {
         const uint32_t frame = first_frame + fi * frame_stride;
-        const int set = pipe ? (int)(t->flip++ & 1u) : 0;
+        const int set = pipe ? (int)(t->flip & 1u) : 0;
+        const int slot = pipe ? (int)(t->flip % (uint32_t)mipt_tracer::kRing) : 0;
+        if (pipe) t->flip++;
         hipStream_t S = set ? t->aux : t->stream;
-        float* sample = set ? t->sample2 : t->sample;
+        float* sample = t->ring[slot];
         uint32_t* counts = set ? t->counts2 : t->counts;
-        if (set) t->auxBusy = true;
-        t->lastSet = set;
+        if (pipe) t->pipeBusy = true;
+        t->lastSlot = slot;
+        if (pipe && t->foldValid[slot]) HIPCHK(t, hipStreamWaitEvent(S, t->foldEv[slot], 0));      // the slot's previous frame has been folded
         HIPCHK(t, hipMemsetAsync(sample, 0, (size_t)npix * 16, S));
         if (t->countPixelRays) HIPCHK(t, hipMemsetAsync(t->pixelRays, 0, (size_t)npix * 4, S));
         LevelArgs A;
@@ -681,14 +702,15 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
             HIPCHK(t, hipEventRecord(kb, S));
         }
         t->pending.emplace_back(ka, kb);
-        // fold into the caller's buffers in frame order: after the previous frame's fold, which may sit on the other stream
-        if (pipe && t->accValid[1 - set]) HIPCHK(t, hipStreamWaitEvent(S, t->accEv[1 - set], 0));
+        // fold into the caller's buffers, in frame order
+        hipStream_t F = pipe ? t->fold : S;
+        if (pipe) { HIPCHK(t, hipEventRecord(t->kernEv[slot], S)); HIPCHK(t, hipStreamWaitEvent(F, t->kernEv[slot], 0)); }
         const float weight = (float)(1.0 / (frame + 1.0));       // CUDATracerProg.cu:878
         mipt_tracer::LevelEv ae{ nullptr, nullptr, -1 };
-        if (t->profileLevels) { HIPCHK(t, hipEventCreate(&ae.a)); HIPCHK(t, hipEventCreate(&ae.b)); HIPCHK(t, hipEventRecord(ae.a, S)); }
-        launch_accumulate(sample, acc_dev, ldr_dev, weight, sum_mode, 0, npix, S);
-        if (t->profileLevels) { HIPCHK(t, hipEventRecord(ae.b, S)); t->levelPending.push_back(ae); }
-        HIPCHK(t, hipEventRecord(t->accEv[set], S)); t->accValid[set] = true;
+        if (t->profileLevels) { HIPCHK(t, hipEventCreate(&ae.a)); HIPCHK(t, hipEventCreate(&ae.b)); HIPCHK(t, hipEventRecord(ae.a, F)); }
+        launch_accumulate(sample, acc_dev, ldr_dev, weight, sum_mode, 0, npix, F);
+        if (t->profileLevels) { HIPCHK(t, hipEventRecord(ae.b, F)); t->levelPending.push_back(ae); }
+        if (pipe) { HIPCHK(t, hipEventRecord(t->foldEv[slot], F)); t->foldValid[slot] = true; }
         t->frames++;
     }
     HIPCHK(t, hipGetLastError());
@@ -712,11 +734,11 @@ int mipt_tonemap(mipt_tracer* t, const float* acc_dev, float scale, uint32_t n_p
 int mipt_last_sample(mipt_tracer* t, float* rgb_host, uint32_t* rays_host, uint32_t n_pixels) {
     if (!t) return MIPT_E_INVALID;
     if (use(t)) return MIPT_E_HIP;
-    if (n_pixels > (t->lastSet ? t->sample2Pixels : t->samplePixels)) return fail(t, MIPT_E_INVALID, "no sample of that size");
+    if (n_pixels > (t->lastSlot ? t->ringPixels : t->samplePixels)) return fail(t, MIPT_E_INVALID, "no sample of that size");
     HIPCHK(t, hipStreamSynchronize(t->stream));
     if (rgb_host) {
         std::vector<float> tmp((size_t)n_pixels * 4);
-        HIPCHK(t, hipMemcpy(tmp.data(), t->lastSet ? t->sample2 : t->sample, tmp.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(t, hipMemcpy(tmp.data(), t->lastSlot ? t->ring[t->lastSlot] : t->sample, tmp.size() * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n_pixels; i++) { rgb_host[i * 3] = tmp[i * 4]; rgb_host[i * 3 + 1] = tmp[i * 4 + 1]; rgb_host[i * 3 + 2] = tmp[i * 4 + 2]; }
     }
     if (rays_host) {
