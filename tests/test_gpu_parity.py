@@ -477,3 +477,39 @@ def test_frame_pipeline_equals_serial_frames(tracer, ptlib):
     for k in (2, 4):
         assert np.abs(pip[k].astype(int) - ser[k].astype(int)).max() <= 1
     assert pip[5] == ser[5] and pip[6] == ser[6] == 17                 # same rays, same frame count
+
+
+def test_caller_supplied_stream_orders_everything_there(tracer, ptlib):
+    """mipt_set_stream: frames and clears run on the caller's stream, in order, so the caller can consume the buffers
+    on that stream without mipt_synchronize; the frame pipeline is off.  (A raw HIP stream from the runtime libmipt
+    itself is linked against; bench.py does the same with torch's tensors.)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    sc = ptlib.Scene(tracer, ptlib.builtin_scene(0))
+    w, h = 160, 96
+    nbytes = w * h * 16
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), w, h, 5)
+    acc0 = tracer.malloc(nbytes)
+    tracer.memset(acc0, 0, nbytes)
+    tracer.render(sc, s, 0, 6, acc0)                                  # reference result on the tracer's own streams
+    ref = tracer.download(acc0, (h, w, 4), np.float32)
+    acc = tracer.malloc(nbytes)
+    st = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    got = np.zeros((h, w, 4), np.float32)
+    try:
+        tracer.set_stream(st)
+        tracer.memset(acc, 0, nbytes)                                  # on the caller's stream now
+        tracer.render(sc, s, 0, 6, acc)
+        # consumed on the same stream, no library synchronisation in between (2 = hipMemcpyDeviceToHost)
+        assert hip.hipMemcpyAsync(got.ctypes.data_as(C.c_void_p), C.c_void_p(acc), C.c_size_t(nbytes), 2, st) == 0
+        assert hip.hipStreamSynchronize(st) == 0
+    finally:
+        tracer.set_stream(None)
+        hip.hipStreamDestroy(st)
+    assert rel_err(got, ref).max() < RTOL * 4
+    # back on its own streams the tracer pipelines again and still agrees
+    tracer.memset(acc, 0, nbytes)
+    tracer.render(sc, s, 0, 6, acc)
+    assert rel_err(tracer.download(acc, (h, w, 4), np.float32), ref).max() < RTOL * 4
+    tracer.free(acc), tracer.free(acc0)
