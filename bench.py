@@ -133,7 +133,15 @@ def main():
     t.set_option("integrator", a.integrator)
     t.set_option("estimator", a.estimator)
     t.set_option("pipeline_frames", a.pipeline)
-    sc = pt.Scene(t, data, node_width=a.node_width)
+    if a.workload == "grid" and world > 1:
+        # 10 M triangles: rank 0 builds the BVH and writes the cache file, the others load it instead of building eight times
+        cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mipt_bench_grid{a.grid_n}_w{a.node_width}.bvh")
+        sc = pt.Scene(t, data, node_width=a.node_width, bvh_cache=cache) if rank == 0 else None
+        dist.barrier()
+        if rank != 0:
+            sc = pt.Scene(t, data, node_width=a.node_width, bvh_cache=cache)
+    else:
+        sc = pt.Scene(t, data, node_width=a.node_width)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     ldr = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
