@@ -88,8 +88,16 @@ def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0)
                 miss_all=1.0 - full["hits"] / max(full["rays"], 1))
 
 
+def dbg(msg):
+    if os.environ.get("BENCH_DEBUG"):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
+    if os.environ.get("BENCH_DEBUG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get("BENCH_DEBUG_DUMP_AFTER", "40")), exit=False)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -125,6 +133,7 @@ def main():
         cam = pt.make_camera((-7.0, 4.0, 0.0), 0.0, 2.0, float(np.float32(np.pi / 3)))
     settings = pt.make_settings(cam, W, H, depth)
 
+    dbg("scene data ready")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     t = pt.Tracer(local)
@@ -142,6 +151,7 @@ def main():
             sc = pt.Scene(t, data, node_width=a.node_width, bvh_cache=cache)
     else:
         sc = pt.Scene(t, data, node_width=a.node_width)
+    dbg("scene uploaded")
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     ldr = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
@@ -159,11 +169,15 @@ def main():
 
     for i in range(a.warmup):
         step(i)
+    dbg("warm-up frames queued")
     if world > 1:   # warm the RCCL path too, then start the timed run from a clean sum buffer
         t.synchronize()
+        dbg("warm-up frames done")
         warm = acc.clone() if a.backend == "nccl" else acc.cpu()
         dist.reduce(warm, dst=0, op=dist.ReduceOp.SUM)
+        dbg("warm-up reduce done")
         acc.zero_()
+    dbg("warm-up done")
     barrier()
     t.reset_counters()
     t.set_option("profile_levels", 1)
@@ -180,6 +194,7 @@ def main():
             t.tonemap(mean.data_ptr(), 1.0, W * H, ldr.data_ptr())
     barrier()
     dt = time.perf_counter() - t0
+    dbg("timed region done")
     t.set_option("profile_levels", 0)
 
     cnt = t.counters()

@@ -276,10 +276,10 @@ int mipt_create(int device, mipt_tracer** out) {
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) t->numCU = cu;
     if (hipStreamCreateWithFlags(&t->own, hipStreamNonBlocking) != hipSuccess) { delete t; return MIPT_E_HIP; }
     t->stream = t->own;
-    int prLow = 0, prHigh = 0;
-    hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
+    // (all three streams at normal priority: a high-priority fold stream bought nothing, and when two processes share
+    // one GPU its queue, parked on an event wait, kept the queue that had to signal it from being scheduled)
     bool ok = hipStreamCreateWithFlags(&t->aux, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithPriority(&t->fold, hipStreamNonBlocking, prHigh) == hipSuccess &&
+              hipStreamCreateWithFlags(&t->fold, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&t->joinEv, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < mipt_tracer::kRing && ok; i++)
         ok = hipEventCreateWithFlags(&t->kernEv[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&t->foldEv[i], hipEventDisableTiming) == hipSuccess;
