@@ -1,5 +1,5 @@
 """BASELINE config C5 stand-in: displaced-grid stress scene (n x n quads = 2 n^2 triangles), single diffuse material,
-synthetic HDRI, 3840x2160, maxDepth 4.  usage: stress_grid.py n [frames]"""
+synthetic HDRI, 3840x2160, maxDepth 4.  usage: stress_grid.py n [frames]   (node visits / triangle tests per ray for the roofline: bench.py --workload grid)"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -19,13 +19,3 @@ t.render(sc, s, 0, 1, acc); t.synchronize(); t.reset_counters()
 t0 = time.perf_counter(); t.render(sc, s, 1, frames, acc); t.synchronize(); dt = time.perf_counter() - t0
 c = t.counters()
 print(f"grid {n}: {dt/frames*1e3:.2f} ms/frame, {c.rays/frames/1e6:.1f} Mrays/frame, {c.rays/dt/1e6:.0f} Mrays/s", flush=True)
-if len(sys.argv) > 3:   # oracle sample for N_node / N_tri
-    from oracle import orc
-    o = orc.Scene(data); o.set_flat_bvh(nodes, refs, sc.bvh_width)
-    st_tot = [0, 0, 0]
-    for y in range(0, H, H // 8):
-        r = o.render(s, orc.ISECT_FLAT, orc.RNG_NODE, orc.MATH_DET, 1, 1, rect=(0, y, W, y + 1), want_ldr=False, nthreads=16)
-        st_tot[0] += r["stats"].rays; st_tot[1] += r["stats"].node_visits; st_tot[2] += r["stats"].tri_tests
-    nn, nt = st_tot[1] / st_tot[0], st_tot[2] / st_tot[0]
-    b = 64 * nn + 48 * nt + 64
-    print(f"oracle sample: N_node {nn:.2f} N_tri {nt:.2f} B_ray {b:.0f} -> algorithmic {c.rays/dt*b/1e9:.0f} GB/s", flush=True)
