@@ -69,3 +69,20 @@ def test_host_only_scene_errors(ptlib):
         ptlib.Scene(None, data, builder=7)
     with pytest.raises(ptlib.MiptError):
         ptlib.Scene(None, data, max_leaf=16)
+
+
+def test_only_the_permitted_places_touch_the_oracle():
+    # oracle/ is test infrastructure: besides tests/, only __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it
+    import re
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b|.*liboracle|.*orc_[a-z_]+\()", re.M)
+    for sub in ("scripts", "cudapathtracer_amd"):
+        for root, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".cpp", ".hpp", ".h", ".hip")) or f == "Makefile":
+                    assert not pat.search(open(os.path.join(root, f), errors="ignore").read()), os.path.join(root, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle import", bench)]
+    assert len(uses) == 1 and bench.rfind("def oracle_sample", 0, uses[0]) > bench.rfind("\ndef ", 0, bench.rfind("def oracle_sample", 0, uses[0]))
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    for m in re.finditer(r"from oracle import|import oracle", entry):
+        assert entry.rfind("def smoke", 0, m.start()) > entry.rfind("def build", 0, m.start())
