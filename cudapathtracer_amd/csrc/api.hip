@@ -493,6 +493,7 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
     memcpy(s->dev.skyColor, d->sky.color, 12); memcpy(s->dev.skyDir, d->sky.dir, 12); s->dev.skyIntensity = d->sky.intensity;
     s->dev.nNodes = (uint32_t)(s->hNodes.size() / 16); s->dev.nRefs = (uint32_t)bo.refTri.size();
     s->dev.wide = bo.width == 4 ? 1u : 0u;
+    s->dev.stackNeed = bo.stackNeed;
     if (t) hipDeviceSynchronize();
     *out = s;
     return MIPT_OK;
@@ -670,7 +671,7 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
             StackArgs SA;
             SA.S = sc->dev; SA.F = A.F; SA.stack = set ? t->wstack2 : t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes;
             // min_descend_lanes auto: 8 for an LDS-resident scene, 24 otherwise (measured optima, profiles/r1/exp_min_descend.log)
-            const bool ldsScene = !sc->dev.wide && sc->dev.nNodes * 4 + sc->dev.nRefs * 3 <= 256;
+            const bool ldsScene = !sc->dev.wide && sc->dev.nNodes * 4 + sc->dev.nRefs * 3 <= 256 && sc->dev.stackNeed <= 8;
             SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (ldsScene ? 8 : 24));
             SA.pixCounter = counts; SA.nee = nee ? 1u : 0u;
             SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npix;

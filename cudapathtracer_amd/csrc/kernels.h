@@ -21,6 +21,7 @@ struct SceneDev {
     float skyColor[3]; float skyDir[3]; float skyIntensity;
     uint32_t nNodes, nRefs;
     uint32_t wide;            // 0: BVH2 nodes, 1: quantised 4-wide nodes
+    uint32_t stackNeed;       // the builder's bound of traversal-stack entries per ray (incl. the sentinel)
     const float* envCdf;      // estimator 1: rowCdf[envH+1], then envH rows of colCdf[envW+1]; nullptr without an env map
     float neeScale;           // pi / (0.98 * envW * envH)
     const float* emitTri;     // estimator 1: emissive triangles, 15 floats each [v0 e1 e2 unit-normal Le]; nullptr if none

@@ -85,6 +85,11 @@ MIPT_DEV bool mt_test(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, int id, int b
          else { (out_) = (deep_)[(sp_) - kLdsStack]; asm volatile("" : "+v"(out_)); }                    /* ... and scratch_load apart */ \
     } while (0)
 
+// LDS-resident scenes are only traversed this way when the builder's stack bound fits the LDS part (the host checks
+// SceneDev::stackNeed <= kLdsStack), so their pushes and pops need no scratch branch at all.
+#define MIPT_STACK_PUSH_L(lds_, sp_, x_) do { (lds_)[(sp_) * kBlock] = (x_); (sp_)++; } while (0)
+#define MIPT_STACK_POP_L(lds_, sp_, out_) do { (sp_)--; (out_) = (lds_)[(sp_) * kBlock]; } while (0)
+
 // Closest hit (TraceRay, CUDATracerProg.cu:543-794) on the flat scene BVH.  Near child first, far child pushed;
 // leaves are tested when they become current; hitT shrinks as hits are found and culls later box tests.
 // With LDS_SCENE the whole node + reference stream has been copied into LDS by the block (scenes of a few KB, e.g. the
@@ -573,7 +578,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     HitRec h; h.t = __builtin_inff(); h.u = h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
     uint32_t cur = kTerm;
     uint32_t* const lstk = ldsStack + threadIdx.x;
-    uint32_t deep[(WIDE ? kWideStackCap : kStackCap) - kLdsStack];
+    uint32_t deep[LDS_SCENE ? 1 : (WIDE ? kWideStackCap : kStackCap) - kLdsStack];
     int tsp = 0;
     uint32_t traced = 0, shadowTraced = 0;
     MIPT_PROF(unsigned long long pf[12] = {};)
@@ -717,7 +722,8 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     }
                     r = ray_pre(o, d);
                     h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
-                    tsp = 0; MIPT_STACK_PUSH(lstk, deep, tsp, kTerm);
+                    tsp = 0;
+                    if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, kTerm); else MIPT_STACK_PUSH(lstk, deep, tsp, kTerm);
                     cur = 0;
                     active = true;
                     traced++;
@@ -771,11 +777,11 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                         if (h0 && h1) {
                             uint32_t second = c1;
                             if (t1 < t0) { first = c1; second = c0; }
-                            MIPT_STACK_PUSH(lstk, deep, tsp, second);
+                            if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, second); else MIPT_STACK_PUSH(lstk, deep, tsp, second);
                         }
                         cur = first;
                     } else {
-                        MIPT_STACK_POP(lstk, deep, tsp, cur);
+                        if constexpr (LDS_SCENE) MIPT_STACK_POP_L(lstk, tsp, cur); else MIPT_STACK_POP(lstk, deep, tsp, cur);
                     }
                 }
             }
@@ -791,7 +797,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     int id = (int)__float_as_uint(a.w);
                     if (mt_test(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) { h.t = tt; h.u = uu; h.v = vv; h.front = ff; h.ref = (int)i; h.tri = id; }
                 }
-                MIPT_STACK_POP(lstk, deep, tsp, cur);
+                if constexpr (LDS_SCENE) MIPT_STACK_POP_L(lstk, tsp, cur); else MIPT_STACK_POP(lstk, deep, tsp, cur);
                 if constexpr (NEE) if ((pix & kShadowBit) && h.tri >= 0) cur = kTerm;      // occlusion ray: any hit ends it
             }
         }
@@ -831,7 +837,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
 }
 
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
-    const bool lds = !a.S.wide && a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec;
+    const bool lds = !a.S.wide && a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec && a.S.stackNeed <= (uint32_t)kLdsStack;
     if (a.nee) {
         if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
         else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
