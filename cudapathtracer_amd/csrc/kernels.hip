@@ -24,7 +24,7 @@ constexpr uint32_t kTerm = 0xFFFFFFFFu;
 constexpr int kStackCap = 64;      // == kMaxBvhDepth of the builder
 constexpr int kWideStackCap = 96;  // == kMaxWideStack of the builder (4-wide nodes push up to three entries per level)
 constexpr uint32_t kEmptyRef = 0x80000000u;
-constexpr int kLdsStack = 8;       // entries per lane kept in LDS; deeper entries spill to scratch
+constexpr int kLdsStack = 12;      // entries per lane kept in LDS; deeper entries spill to scratch
 
 struct HitRec { float t, u, v; int ref; int tri; bool front; };   // ref = reference index, tri = global triangle id
 
@@ -464,8 +464,8 @@ void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s) {
 // 256 * maxDepth + 256 entries per wave and the kernel raises an error flag instead of writing past it.
 // =================================================================================================================
 // shade-queue entries per wave (a terminated ray that finds it full parks one round later); sized so that a
-// 256-thread block uses exactly a quarter of the CU's 160 KiB: 4 x cap x 64 B + 8 KiB traversal stacks (+ 4 KiB scene)
-template <bool LDS_SCENE> struct SqCap { static constexpr int value = LDS_SCENE ? 112 : 128; };
+// 256-thread block uses exactly a quarter of the CU's 160 KiB: 4 x cap x 64 B + 12 KiB traversal stacks (+ 4 KiB scene); 12 stack entries / cap 112 measured better than 8 / 128 and 16 / 96
+template <bool LDS_SCENE> struct SqCap { static constexpr int value = LDS_SCENE ? 96 : 112; };
 constexpr int kSqWords = 16;         // dwords per entry, SoA by dword: conflict-free LDS access
 
 template <bool LDS_SCENE>
