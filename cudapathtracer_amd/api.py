@@ -85,6 +85,7 @@ lib.mipt_get_level_profile.argtypes = [_vp, C.POINTER(LevelProfile)]
 lib.mipt_scene_create.argtypes = [_vp, C.POINTER(SceneDesc), C.POINTER(_vp)]
 lib.mipt_scene_destroy.argtypes = [_vp]
 lib.mipt_scene_destroy.restype = None
+lib.mipt_scene_refit.argtypes = [_vp, _vp]
 lib.mipt_scene_get_bvh.argtypes = [_vp, _vp, C.POINTER(C.c_uint32), _vp, C.POINTER(C.c_uint32)]
 lib.mipt_scene_triangle_count.argtypes = [_vp]
 lib.mipt_scene_triangle_count.restype = C.c_uint32
@@ -270,6 +271,14 @@ class Scene:
         if rc != 0:
             raise MiptError(f"mipt_scene_create: {rc} {tracer.last_error() if tracer else ''}")
         self.h = h
+
+    def refit(self, data):
+        """Same topology, moved vertices / edited materials: re-fits the BVH boxes and overwrites the device buffers."""
+        desc, keep = data.fill_desc(SceneDesc, MeshDesc)
+        rc = lib.mipt_scene_refit(self.h, C.byref(desc))
+        if rc != 0:
+            raise MiptError(f"mipt_scene_refit: {rc} {self.tracer.last_error() if self.tracer else ''}")
+        self.data = data
 
     @property
     def bvh_width(self):

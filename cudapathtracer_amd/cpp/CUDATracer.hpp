@@ -26,20 +26,7 @@ class CUDAScene {
 public:
     // bvhCachePath: optional BVH cache file (mipt_scene_desc::bvhCachePath); $MIPT_BVH_CACHE is used when it is null
     explicit CUDAScene(const Scene& scn, unsigned bvhBuilder = MIPT_BVH_SBVH, const char* bvhCachePath = nullptr) {
-        std::vector<mipt_mesh_desc> meshes(scn.objects.size());
-        for (size_t i = 0; i < scn.objects.size(); i++) {
-            const Mesh& m = scn.objects[i];
-            meshes[i].vertices = reinterpret_cast<const mipt_vertex*>(m.GetVertices().data());
-            meshes[i].vertexCnt = (uint32_t)m.GetVertices().size();
-            meshes[i].indices = m.GetIndices().data();
-            meshes[i].indicesCnt = (uint32_t)m.GetIndices().size();
-            std::memset(&meshes[i].material, 0, sizeof(mipt_material));
-            std::memcpy(&meshes[i].material, &m.GetMat(), 45);
-        }
-        mipt_scene_desc d{};
-        d.meshes = meshes.data(); d.meshCnt = (uint32_t)meshes.size();
-        std::memcpy(&d.sky, &scn.skyLight, sizeof(mipt_skylight));
-        if (!scn.envMap.empty()) { d.envMap = scn.envMap.data(); d.envW = scn.envMapDim.x; d.envH = scn.envMapDim.y; }
+        std::vector<mipt_mesh_desc> meshes; mipt_scene_desc d = Describe(scn, meshes);
         d.bvhBuilder = bvhBuilder;
         d.bvhCachePath = bvhCachePath ? bvhCachePath : std::getenv("MIPT_BVH_CACHE");
         detail::Check(mipt_scene_create(detail::DefaultTracer(), &d, &_s), "mipt_scene_create");
@@ -53,7 +40,30 @@ public:
     mipt_scene* handle() { return _s; }
     unsigned meshCnt() const { return _meshCnt; }
     bool BvhWasCached() const { return mipt_scene_bvh_was_cached(_s) != 0; }
+    // Same meshes with moved vertices and/or edited materials (an animation step): BVH boxes re-fitted, device buffers
+    // overwritten in place -- mipt_scene_refit.  The reference would build a new CUDAScene.
+    void Refit(const Scene& scn) {
+        std::vector<mipt_mesh_desc> meshes; mipt_scene_desc d = Describe(scn, meshes);
+        detail::Check(mipt_scene_refit(_s, &d), "mipt_scene_refit");
+    }
 private:
+    static mipt_scene_desc Describe(const Scene& scn, std::vector<mipt_mesh_desc>& meshes) {
+        meshes.resize(scn.objects.size());
+        for (size_t i = 0; i < scn.objects.size(); i++) {
+            const Mesh& m = scn.objects[i];
+            meshes[i].vertices = reinterpret_cast<const mipt_vertex*>(m.GetVertices().data());
+            meshes[i].vertexCnt = (uint32_t)m.GetVertices().size();
+            meshes[i].indices = m.GetIndices().data();
+            meshes[i].indicesCnt = (uint32_t)m.GetIndices().size();
+            std::memset(&meshes[i].material, 0, sizeof(mipt_material));
+            std::memcpy(&meshes[i].material, &m.GetMat(), 45);
+        }
+        mipt_scene_desc d{};
+        d.meshes = meshes.data(); d.meshCnt = (uint32_t)meshes.size();
+        std::memcpy(&d.sky, &scn.skyLight, sizeof(mipt_skylight));
+        if (!scn.envMap.empty()) { d.envMap = scn.envMap.data(); d.envW = scn.envMapDim.x; d.envH = scn.envMapDim.y; }
+        return d;
+    }
     mipt_scene* _s = nullptr;
     unsigned _meshCnt = 0;
 };

@@ -75,6 +75,8 @@ struct mipt_scene {
     void* dEmitTri = nullptr; void* dEmitCdf = nullptr;
     std::vector<float> hEmitTri, hEmitCdf;      // estimator 1: emissive triangles (15 floats each) and their area CDF
     std::vector<float> hNodes, hRefs;    // host copies for mipt_scene_get_bvh
+    std::vector<uint32_t> hRefTri;       // triangle id per reference (mipt_scene_refit)
+    uint32_t nMeshes = 0; size_t emitCap = 0;   // emitCap: emissive triangles the device buffers hold
     uint32_t nTris = 0;
     uint32_t bvhWidth = 2;
     bool bvhFromCache = false;
@@ -258,6 +260,53 @@ bool save_bvh_cache(const char* path, uint64_t key, uint32_t nTris, const BvhOut
     return ok;
 }
 
+// flattens the meshes of a desc: triangle positions, mesh id per triangle, and the 12-float shading record per triangle
+int gather_geometry(mipt_tracer* t, const mipt_scene_desc* d, std::vector<TriPos>& tris, std::vector<uint32_t>& triMesh, std::vector<float>& shade) {
+    if (d->meshCnt && !d->meshes) return fail(t, MIPT_E_INVALID, "meshes is null");
+    for (uint32_t m = 0; m < d->meshCnt; m++) {
+        const mipt_mesh_desc& md = d->meshes[m];
+        if (md.indicesCnt % 3) return fail(t, MIPT_E_INVALID, "indicesCnt is not a multiple of 3");
+        if (md.indicesCnt && (!md.indices || !md.vertices)) return fail(t, MIPT_E_INVALID, "mesh arrays are null");
+        for (uint32_t i = 0; i < md.indicesCnt; i += 3) {
+            TriPos tp; float nn[3][3];
+            for (int k = 0; k < 3; k++) {
+                uint32_t vi = md.indices[i + k];
+                if (vi >= md.vertexCnt) return fail(t, MIPT_E_INVALID, "vertex index out of range");
+                memcpy(tp.v[k], md.vertices[vi].position, 12);
+                // unit vertex normal, as the reference normalises at hit time (CUDATracerProg.cu:290-293)
+                const float* n = md.vertices[vi].normal;
+                float len = sqrtf(hdot(n, n));
+                for (int a = 0; a < 3; a++) nn[k][a] = (n[a] * 1.f) / len;
+            }
+            tris.push_back(tp); triMesh.push_back(m);
+            float rec[12] = { nn[0][0], nn[0][1], nn[0][2], 0, nn[1][0], nn[1][1], nn[1][2], 0, nn[2][0], nn[2][1], nn[2][2], 0 };
+            memcpy(&rec[3], &m, 4);
+            shade.insert(shade.end(), rec, rec + 12);
+        }
+    }
+    return MIPT_OK;
+}
+
+// reference records (base vertex, two edges, triangle id, mesh id) in leaf order, and the 12-float material records
+void fill_refs(const std::vector<uint32_t>& refTri, const std::vector<TriPos>& tris, const std::vector<uint32_t>& triMesh, std::vector<float>& refs) {
+    refs.resize(refTri.size() * 12);
+    for (size_t r = 0; r < refTri.size(); r++) {
+        uint32_t g = refTri[r]; const TriPos& tp = tris[g];
+        float* R = &refs[r * 12];
+        for (int a = 0; a < 3; a++) { R[a] = tp.v[0][a]; R[4 + a] = tp.v[1][a] - tp.v[0][a]; R[8 + a] = tp.v[2][a] - tp.v[0][a]; }
+        memcpy(&R[3], &g, 4); memcpy(&R[7], &triMesh[g], 4); R[11] = 0.f;
+    }
+}
+void fill_materials(const mipt_scene_desc* d, std::vector<float>& mats) {
+    mats.assign((size_t)std::max<uint32_t>(d->meshCnt, 1) * 12, 0.f);
+    for (uint32_t m = 0; m < d->meshCnt; m++) {
+        const mipt_material& mm = d->meshes[m].material; float* M = &mats[(size_t)m * 12];
+        M[0] = mm.color[0]; M[1] = mm.color[1]; M[2] = mm.color[2]; M[3] = mm.roughness;
+        M[4] = mm.metallic; M[5] = mm.opacity; M[6] = mm.n; M[7] = mm.emissiveStrength;
+        M[8] = mm.emissiveColor[0]; M[9] = mm.emissiveColor[1]; M[10] = mm.emissiveColor[2]; M[11] = 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -400,31 +449,10 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
     if (!d || !out) return MIPT_E_INVALID;
     *out = nullptr;
     if (t && use(t)) return MIPT_E_HIP;     // t == NULL: host-only scene (BVH build + mipt_scene_get_bvh, no upload)
-    if (d->meshCnt && !d->meshes) return fail(t, MIPT_E_INVALID, "meshes is null");
     std::vector<TriPos> tris;
     std::vector<uint32_t> triMesh;
     std::vector<float> shade;     // 12 per triangle
-    for (uint32_t m = 0; m < d->meshCnt; m++) {
-        const mipt_mesh_desc& md = d->meshes[m];
-        if (md.indicesCnt % 3) return fail(t, MIPT_E_INVALID, "indicesCnt is not a multiple of 3");
-        if (md.indicesCnt && (!md.indices || !md.vertices)) return fail(t, MIPT_E_INVALID, "mesh arrays are null");
-        for (uint32_t i = 0; i < md.indicesCnt; i += 3) {
-            TriPos tp; float nn[3][3];
-            for (int k = 0; k < 3; k++) {
-                uint32_t vi = md.indices[i + k];
-                if (vi >= md.vertexCnt) return fail(t, MIPT_E_INVALID, "vertex index out of range");
-                memcpy(tp.v[k], md.vertices[vi].position, 12);
-                // unit vertex normal, as the reference normalises at hit time (CUDATracerProg.cu:290-293)
-                const float* n = md.vertices[vi].normal;
-                float len = sqrtf(hdot(n, n));
-                for (int a = 0; a < 3; a++) nn[k][a] = (n[a] * 1.f) / len;
-            }
-            tris.push_back(tp); triMesh.push_back(m);
-            float rec[12] = { nn[0][0], nn[0][1], nn[0][2], 0, nn[1][0], nn[1][1], nn[1][2], 0, nn[2][0], nn[2][1], nn[2][2], 0 };
-            memcpy(&rec[3], &m, 4);
-            shade.insert(shade.end(), rec, rec + 12);
-        }
-    }
+    if (int rc = gather_geometry(t, d, tris, triMesh, shade)) return rc;
     BvhParams bp;
     bp.builder = d->bvhBuilder;
     if (bp.builder != MIPT_BVH_SBVH && bp.builder != MIPT_BVH_MEDIAN) return fail(t, MIPT_E_INVALID, "unknown bvhBuilder");
@@ -448,22 +476,11 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
     }
 
     mipt_scene* s = new mipt_scene();
-    s->t = t; s->nTris = (uint32_t)tris.size(); s->bvhFromCache = cached; s->bvhWidth = bo.width;
+    s->t = t; s->nMeshes = d->meshCnt; s->nTris = (uint32_t)tris.size(); s->bvhFromCache = cached; s->bvhWidth = bo.width;
     s->hNodes = std::move(bo.nodes);
-    s->hRefs.resize(bo.refTri.size() * 12);
-    for (size_t r = 0; r < bo.refTri.size(); r++) {
-        uint32_t g = bo.refTri[r]; const TriPos& tp = tris[g];
-        float* R = &s->hRefs[r * 12];
-        for (int a = 0; a < 3; a++) { R[a] = tp.v[0][a]; R[4 + a] = tp.v[1][a] - tp.v[0][a]; R[8 + a] = tp.v[2][a] - tp.v[0][a]; }
-        memcpy(&R[3], &g, 4); memcpy(&R[7], &triMesh[g], 4); R[11] = 0.f;
-    }
-    std::vector<float> mats((size_t)std::max<uint32_t>(d->meshCnt, 1) * 12, 0.f);
-    for (uint32_t m = 0; m < d->meshCnt; m++) {
-        const mipt_material& mm = d->meshes[m].material; float* M = &mats[(size_t)m * 12];
-        M[0] = mm.color[0]; M[1] = mm.color[1]; M[2] = mm.color[2]; M[3] = mm.roughness;
-        M[4] = mm.metallic; M[5] = mm.opacity; M[6] = mm.n; M[7] = mm.emissiveStrength;
-        M[8] = mm.emissiveColor[0]; M[9] = mm.emissiveColor[1]; M[10] = mm.emissiveColor[2]; M[11] = 0.f;
-    }
+    s->hRefTri = bo.refTri;
+    fill_refs(s->hRefTri, tris, triMesh, s->hRefs);
+    std::vector<float> mats; fill_materials(d, mats);
     if (d->envMap && d->envW && d->envH) build_env_cdf(d->envMap, d->envW, d->envH, s->hEnvCdf);
     const float emitScale = build_emitters(d, tris, triMesh, s->hEmitTri, s->hEmitCdf);
     auto upload = [&](void** dst, const void* src, size_t bytes) -> bool {
@@ -489,6 +506,7 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
     s->dev.envCdf = (const float*)s->dEnvCdf;
     s->dev.emitTri = (const float*)s->dEmitTri; s->dev.emitCdf = (const float*)s->dEmitCdf;
     s->dev.nEmit = s->dEmitCdf ? (uint32_t)(s->hEmitCdf.size() - 1) : 0u; s->dev.emitScale = emitScale;
+    s->emitCap = s->dev.nEmit;
     s->dev.neeScale = s->dEnv ? (float)(M_PI / 0.98 / ((double)d->envW * (double)d->envH)) : 0.f;
     memcpy(s->dev.skyColor, d->sky.color, 12); memcpy(s->dev.skyDir, d->sky.dir, 12); s->dev.skyIntensity = d->sky.intensity;
     s->dev.nNodes = (uint32_t)(s->hNodes.size() / 16); s->dev.nRefs = (uint32_t)bo.refTri.size();
@@ -511,6 +529,52 @@ void mipt_scene_destroy(mipt_scene* s) {
     if (s->dEmitTri) hipFree(s->dEmitTri);
     if (s->dEmitCdf) hipFree(s->dEmitCdf);
     delete s;
+}
+
+// Moved vertices / edited materials on an uploaded scene (the use the reference's CUDAScene::GetMeshMutable,
+// CUDATracer.hpp:217-221, points at but never makes): the tree keeps its shape, boxes are re-fitted, the flat buffers are
+// overwritten in place.  Env map and sky are taken from the scene as created.
+int mipt_scene_refit(mipt_scene* s, const mipt_scene_desc* d) {
+    if (!s || !d) return MIPT_E_INVALID;
+    mipt_tracer* t = s->t;
+    if (t && use(t)) return MIPT_E_HIP;
+    if (d->meshCnt != s->nMeshes) return fail(t, MIPT_E_INVALID, "refit: mesh count differs from the scene's");
+    std::vector<TriPos> tris; std::vector<uint32_t> triMesh; std::vector<float> shade;
+    if (int rc = gather_geometry(t, d, tris, triMesh, shade)) return rc;
+    if (tris.size() != s->nTris) return fail(t, MIPT_E_INVALID, "refit: triangle count differs from the scene's");
+    if (s->nTris == 0) return MIPT_OK;
+    BvhOut bo; bo.nodes = s->hNodes; bo.refTri = s->hRefTri; bo.width = s->bvhWidth;
+    std::string err = refit_bvh(bo, tris);
+    if (!err.empty()) return fail(t, MIPT_E_LIMIT, "BVH refit: " + err);
+    std::vector<float> refs, mats, emitTri, emitCdf;
+    fill_refs(s->hRefTri, tris, triMesh, refs);
+    fill_materials(d, mats);
+    const float emitScale = build_emitters(d, tris, triMesh, emitTri, emitCdf);
+    if (t) {
+        // every frame in flight has been joined by use(); the stream of this tracer may still be running them
+        HIPCHK(t, hipStreamSynchronize(t->stream));
+        HIPCHK(t, hipMemcpy(s->dNodes, bo.nodes.data(), bo.nodes.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(t, hipMemcpy(s->dRefs, refs.data(), refs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(t, hipMemcpy(s->dShade, shade.data(), shade.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(t, hipMemcpy(s->dMats, mats.data(), mats.size() * 4, hipMemcpyHostToDevice));
+        const size_t nEmit = emitCdf.empty() ? 0 : emitCdf.size() - 1;
+        if (nEmit > s->emitCap) {           // a material turned emissive: the emitter table grows
+            if (s->dEmitTri) HIPCHK(t, hipFree(s->dEmitTri));
+            if (s->dEmitCdf) HIPCHK(t, hipFree(s->dEmitCdf));
+            s->dEmitTri = s->dEmitCdf = nullptr; s->emitCap = 0;
+            HIPCHK(t, hipMalloc(&s->dEmitTri, nEmit * 15 * 4));
+            HIPCHK(t, hipMalloc(&s->dEmitCdf, (nEmit + 1) * 4));
+            s->emitCap = nEmit;
+        }
+        if (nEmit) {
+            HIPCHK(t, hipMemcpy(s->dEmitTri, emitTri.data(), emitTri.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(t, hipMemcpy(s->dEmitCdf, emitCdf.data(), emitCdf.size() * 4, hipMemcpyHostToDevice));
+        }
+        s->dev.emitTri = (const float*)s->dEmitTri; s->dev.emitCdf = (const float*)s->dEmitCdf;
+        s->dev.nEmit = (uint32_t)nEmit; s->dev.emitScale = emitScale;
+    }
+    s->hNodes.swap(bo.nodes); s->hRefs.swap(refs); s->hEmitTri.swap(emitTri); s->hEmitCdf.swap(emitCdf);
+    return MIPT_OK;
 }
 
 int mipt_scene_get_bvh(const mipt_scene* s, float* nodes, uint32_t* n_nodes, float* refs, uint32_t* n_refs) {

@@ -378,6 +378,45 @@ private:
 // ---- BVH2 -> quantised 4-wide nodes ------------------------------------------------------------------------------
 struct WideChild { uint32_t ref; Box b; };
 
+// writes one 4-wide node at P (16 floats) from up to four child boxes; false when an extent cannot be represented
+inline float scale_of(uint32_t e) { uint32_t b = e << 23; float f; memcpy(&f, &b, 4); return f; }
+bool quantise_node(float* P, const WideChild* ch, int n, const uint32_t* refs) {
+    bool failed = false;
+    Box nb; for (int i = 0; i < n; i++) if (ch[i].b.valid()) nb.grow(ch[i].b);
+    if (!nb.valid()) for (int a = 0; a < 3; a++) nb.mn[a] = nb.mx[a] = 0.f;
+    uint32_t e[3]; uint8_t qlo[3][4] = {}, qhi[3][4] = {};
+    for (int a = 0; a < 3; a++) {
+        const float origin = nb.mn[a];
+        // smallest power of two with 255 * scale >= extent; kept inside [2^-60, 2^40] so the product with a ray's
+        // inverse direction (1 <= |idir| <= 2^80) stays a normal, finite number
+        int ex = 127 - 60;
+        const float ext = nb.mx[a] - origin;
+        while (ex < 167 && 255.0f * scale_of((uint32_t)ex) < ext) ex++;
+        for (;; ex++) {      // widen until every child plane fits (fp32 rounding of the extent can cost one step)
+            bool ok = true;
+            const float sc = scale_of((uint32_t)ex);
+            for (int i = 0; i < n && ok; i++) {
+                if (!ch[i].b.valid()) { qlo[a][i] = 0; qhi[a][i] = 0; continue; }
+                int lo = (int)std::floor((ch[i].b.mn[a] - origin) / sc); lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
+                while (lo > 0 && std::fma((float)lo, sc, origin) > ch[i].b.mn[a]) lo--;
+                int hi = (int)std::ceil((ch[i].b.mx[a] - origin) / sc); hi = hi < 0 ? 0 : hi;
+                while (hi <= 255 && std::fma((float)hi, sc, origin) < ch[i].b.mx[a]) hi++;
+                if (hi > 255 || std::fma((float)lo, sc, origin) > ch[i].b.mn[a]) { ok = false; break; }
+                qlo[a][i] = (uint8_t)lo; qhi[a][i] = (uint8_t)hi;
+            }
+            if (ok) break;
+            if (ex >= 167) { failed = true; break; }     // extent beyond 2^48: not representable
+        }
+        e[a] = (uint32_t)ex;
+    }
+    memcpy(P, nb.mn, 12);
+    const uint32_t ebits = e[0] | (e[1] << 8) | (e[2] << 16);
+    memcpy(P + 3, &ebits, 4);
+    for (int a = 0; a < 3; a++) { memcpy(P + 4 + a, qlo[a], 4); memcpy(P + 7 + a, qhi[a], 4); }
+    memcpy(P + 12, refs, 16);
+    return !failed;
+}
+
 class Collapser {
 public:
     Collapser(const std::vector<float>& n2, std::vector<float>& n4) : N2(n2), N4(n4) {}
@@ -420,41 +459,8 @@ private:
     const std::vector<float>& N2; std::vector<float>& N4;
 
     void quantise(uint32_t self, const WideChild* ch, int n, const uint32_t* refs) {
-        Box nb; for (int i = 0; i < n; i++) if (ch[i].b.valid()) nb.grow(ch[i].b);
-        if (!nb.valid()) for (int a = 0; a < 3; a++) nb.mn[a] = nb.mx[a] = 0.f;
-        uint32_t e[3]; uint8_t qlo[3][4] = {}, qhi[3][4] = {};
-        for (int a = 0; a < 3; a++) {
-            const float origin = nb.mn[a];
-            // smallest power of two with 255 * scale >= extent; kept inside [2^-60, 2^40] so the product with a ray's
-            // inverse direction (1 <= |idir| <= 2^80) stays a normal, finite number
-            int ex = 127 - 60;
-            const float ext = nb.mx[a] - origin;
-            while (ex < 167 && 255.0f * scale_of((uint32_t)ex) < ext) ex++;
-            for (;; ex++) {      // widen until every child plane fits (fp32 rounding of the extent can cost one step)
-                bool ok = true;
-                const float sc = scale_of((uint32_t)ex);
-                for (int i = 0; i < n && ok; i++) {
-                    if (!ch[i].b.valid()) { qlo[a][i] = 0; qhi[a][i] = 0; continue; }
-                    int lo = (int)std::floor((ch[i].b.mn[a] - origin) / sc); lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
-                    while (lo > 0 && std::fma((float)lo, sc, origin) > ch[i].b.mn[a]) lo--;
-                    int hi = (int)std::ceil((ch[i].b.mx[a] - origin) / sc); hi = hi < 0 ? 0 : hi;
-                    while (hi <= 255 && std::fma((float)hi, sc, origin) < ch[i].b.mx[a]) hi++;
-                    if (hi > 255 || std::fma((float)lo, sc, origin) > ch[i].b.mn[a]) { ok = false; break; }
-                    qlo[a][i] = (uint8_t)lo; qhi[a][i] = (uint8_t)hi;
-                }
-                if (ok) break;
-                if (ex >= 167) { failed = true; break; }     // extent beyond 2^48: not representable
-            }
-            e[a] = (uint32_t)ex;
-        }
-        float* P = &N4[(size_t)self * 16];
-        memcpy(P, nb.mn, 12);
-        const uint32_t ebits = e[0] | (e[1] << 8) | (e[2] << 16);
-        memcpy(P + 3, &ebits, 4);
-        for (int a = 0; a < 3; a++) { memcpy(P + 4 + a, qlo[a], 4); memcpy(P + 7 + a, qhi[a], 4); }
-        memcpy(P + 12, refs, 16);
+        if (!quantise_node(&N4[(size_t)self * 16], ch, n, refs)) failed = true;
     }
-    static float scale_of(uint32_t e) { uint32_t b = e << 23; float f; memcpy(&f, &b, 4); return f; }
 };
 
 }  // namespace
@@ -544,6 +550,53 @@ std::string validate_bvh(BvhOut& out, uint32_t nTris) {
     out.stackNeed = need[0] + 1;                                     // + the sentinel
     if (out.stackNeed > (wide ? kMaxWideStack : kMaxBvhDepth)) return "BVH needs a deeper traversal stack than the device has";
     out.duplicates = (uint32_t)(nRefs - nTris);
+    return "";
+}
+
+std::string refit_bvh(BvhOut& out, const std::vector<TriPos>& tris) {
+    const size_t nNodes = out.nodes.size() / 16;
+    if (nNodes == 0) return "empty BVH";
+    const bool wide = out.width == 4;
+    const int fan = wide ? 4 : 2;
+    for (uint32_t t : out.refTri) if (t >= tris.size()) return "reference to a triangle out of range";
+    // discovery order (parents before children), then boxes bottom-up
+    std::vector<uint32_t> order; order.reserve(nNodes);
+    std::vector<uint32_t> todo{ 0u };
+    while (!todo.empty()) {
+        const uint32_t n = todo.back(); todo.pop_back();
+        order.push_back(n);
+        if (order.size() > nNodes) return "BVH is not a tree";
+        uint32_t r[4]; memcpy(r, &out.nodes[(size_t)n * 16 + 12], 16);
+        for (int c = 0; c < fan; c++) if (!(r[c] & kLeafFlag)) { if (r[c] >= nNodes) return "child node index out of range"; todo.push_back(r[c]); }
+    }
+    std::vector<Box> nodeBox(nNodes);
+    std::vector<float> fresh(out.nodes);          // the scene keeps its BVH if a node cannot be re-quantised
+    for (size_t k = order.size(); k-- > 0;) {
+        const uint32_t n = order[k];
+        float* P = &fresh[(size_t)n * 16];
+        uint32_t r[4]; memcpy(r, P + 12, 16);
+        WideChild ch[4];
+        for (int c = 0; c < fan; c++) {
+            ch[c].ref = r[c];
+            if (r[c] & kLeafFlag) {
+                const uint32_t cnt = (r[c] >> 27) & 0xFu, first = r[c] & 0x07FFFFFFu;
+                if ((size_t)first + cnt > out.refTri.size()) return "leaf range out of bounds";
+                for (uint32_t i = first; i < first + cnt; i++) for (int v = 0; v < 3; v++) ch[c].b.grow(tris[out.refTri[i]].v[v]);
+            } else ch[c].b = nodeBox[r[c]];
+            if (ch[c].b.valid()) nodeBox[n].grow(ch[c].b);
+        }
+        if (wide) {
+            if (!quantise_node(P, ch, 4, r)) return "scene extent too large for quantised 4-wide nodes";
+        } else {
+            // a zero-reference leaf (the builder's root padding) has no box of its own: it takes its sibling's
+            for (int c = 0; c < 2; c++) {
+                Box b = ch[c].b.valid() ? ch[c].b : ch[c ^ 1].b;
+                if (!b.valid()) for (int a = 0; a < 3; a++) b.mn[a] = b.mx[a] = 0.f;
+                memcpy(P + c * 6, b.mn, 12); memcpy(P + c * 6 + 3, b.mx, 12);
+            }
+        }
+    }
+    out.nodes.swap(fresh);
     return "";
 }
 

@@ -60,4 +60,10 @@ std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOu
 // referenced.  Sets out.maxDepth / out.duplicates.  Returns empty string when the BVH is safe to traverse.
 std::string validate_bvh(BvhOut& out, uint32_t nTris);     // out.width selects the layout
 
+// Re-fits the boxes of an existing tree to moved triangles (same count; refTri and the tree's shape stay, so do
+// maxDepth and stackNeed): leaf boxes = bounds of the referenced triangles, inner boxes = union of the children,
+// 4-wide nodes re-quantised.  Spatial-split leaves lose their clipping (boxes stay conservative).  On error `out` is
+// unchanged.
+std::string refit_bvh(BvhOut& out, const std::vector<TriPos>& tris);
+
 }  // namespace mipt

@@ -102,6 +102,15 @@ int  mipt_get_level_profile(mipt_tracer*, mipt_level_profile* out);
 /* ---- scene upload: CUDAScene::CUDAScene (CUDATracer.hpp:133-203) ------------------------------------------ */
 int  mipt_scene_create(mipt_tracer*, const mipt_scene_desc*, mipt_scene** out);
 void mipt_scene_destroy(mipt_scene*);
+/* Moved vertices or edited materials on an uploaded scene: what the reference's mutable accessors
+ * (CUDAScene::GetMeshMutable, CUDATracer.hpp:217-221) allow for but nothing there does -- a change needs a new
+ * CUDAScene, i.e. a full BVH build.  `desc` holds the same meshes with the same index buffers (the triangle count of
+ * the scene must match); positions, normals and materials are taken from it, the tree keeps its shape and its boxes
+ * are re-fitted bottom-up (4-wide nodes re-quantised), and the device buffers are overwritten in place after the
+ * tracer's pending frames have finished.  Env map, sky and BVH parameters of the desc are ignored.  Results are those
+ * of a scene created from `desc` (closest hits do not depend on the tree); traversal cost grows as the geometry drifts
+ * from the one the tree was built for, and spatial-split leaves lose their clipping. */
+int  mipt_scene_refit(mipt_scene*, const mipt_scene_desc* desc);
 /* flattened traversal data, for inspection/tests: nodes = 16 floats each
  *   [c0.min xyz][c0.max xyz][c1.min xyz][c1.max xyz][ref0][ref1][0][0]   (ref: bit31 leaf, bits27-30 count, low 27 first; else node index)
  * refs = 12 floats each [v0 xyz, triId][e1 xyz, meshId][e2 xyz, 0].  Pass NULL buffers to query the counts. */
