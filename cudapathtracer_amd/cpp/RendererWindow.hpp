@@ -80,6 +80,8 @@ public:
     // progressive preview: write "<prefix>_<frames>.ppm" after every `every` accumulated frames (0 = off)
     void SetPreview(const std::string& prefix, unsigned every) { previewPrefix = prefix; previewEvery = every; }
     bool SceneBvhWasCached() { return renderScene.BvhWasCached(); }
+    // an animation step: same meshes, moved vertices / edited materials (CUDAScene::Refit); accumulation restarts
+    void UpdateScene(const CUDATracer::Scene& scn) { renderScene.Refit(scn); ResetFrameID(); }
 
     virtual void render() {
         renderer->Trace(renderScene, *renderSettings, (float*)accBuffer->mutable_gpu_data(), (char*)bitmap->mutable_gpu_data());

@@ -219,6 +219,24 @@ int main(int argc, char** argv) {
         EXPECT(w.frame().size() == 32 * 16 * 4 && w.frameID() == 1);
         const float* a = w.accumulation();
         EXPECT(a[3] == 1.0f);                                           // alpha written by the kernel
+        // animation step: the light goes out -> UpdateScene re-fits in place, accumulation restarts, the image is black
+        Scene lit = Scenes::CornellBox(), dark = lit;
+        dark.objects.clear();
+        for (const Mesh& m : lit.objects) { SurfaceMaterial mat = m.GetMat(); mat.emissiveStrength = 0.f; dark.objects.emplace_back(m.GetVertices(), m.GetIndices(), mat); }
+        w.UpdateScene(dark);
+        EXPECT(w.frameID() == 0);
+        w.render();
+        a = w.accumulation();
+        float sum = 0.f; for (int i = 0; i < 32 * 16; i++) sum += a[4 * i] + a[4 * i + 1] + a[4 * i + 2];
+        EXPECT(sum == 0.f);
+        w.UpdateScene(Scenes::CornellBox());
+        w.render();
+        a = w.accumulation();
+        sum = 0.f; for (int i = 0; i < 32 * 16; i++) sum += a[4 * i] + a[4 * i + 1] + a[4 * i + 2];
+        EXPECT(sum > 0.f);
+        bool threw = false;
+        try { w.UpdateScene(Scenes::DefaultScene()); } catch (const std::exception&) { threw = true; }   // another topology
+        EXPECT(threw);
         std::printf("OK\n");
     } catch (const std::exception& e) { std::printf("error: %s\n", e.what()); return 1; }
     return 0;

@@ -513,3 +513,55 @@ def test_caller_supplied_stream_orders_everything_there(tracer, ptlib):
     tracer.render(sc, s, 0, 6, acc)
     assert rel_err(tracer.download(acc, (h, w, 4), np.float32), ref).max() < RTOL * 4
     tracer.free(acc), tracer.free(acc0)
+
+
+def test_refit_on_device_equals_a_fresh_scene(tracer, ptlib, oracle):
+    """mipt_scene_refit: after the vertices move (and a material turns emissive) the uploaded scene renders what a scene
+    created from the new data renders -- same ray trees, and the oracle on the re-fitted BVH agrees as usual."""
+    from test_scene_bvh import _moved
+    rng = np.random.default_rng(5)
+    env = (rng.uniform(0.2, 1.0, (32, 64, 3)) ** 2).astype(np.float32)
+    data = ptlib.builtin_scene(1, env)
+    w, h, depth = 96, 72, 6
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.DEFAULT_CAMERA), w, h, depth)
+    acc, ldr = dev_buffers(tracer, w, h)
+    tracer.set_option("count_pixel_rays", 1)
+    try:
+        for width in (2, 4):
+            sc = ptlib.Scene(tracer, data, node_width=width)
+            tracer.trace(sc, s, acc, ldr)                       # frames in flight when the refit arrives
+            tracer.render(sc, s, 1, 3, acc, ldr)
+            moved = _moved(ptlib, data, 0.2)
+            v, i, m = moved.meshes[0]
+            lit = ptlib.make_material(color=tuple(m.color), roughness=m.roughness, metallic=m.metallic, opacity=m.opacity, n=m.n,
+                                      emissive=(1.0, 0.5, 0.2), strength=6.0)
+            moved = ptlib.SceneData([(v, i, lit)] + moved.meshes[1:], moved.sky, moved.env)
+            sc.refit(moved)
+            fresh = ptlib.Scene(tracer, moved, node_width=width)
+            og, dg = random_rays(20000, 12)
+            a, b = tracer.trace_rays(sc, og, dg), tracer.trace_rays(fresh, og, dg)
+            differ = (a["tri"] != b["tri"]) | (a["t"] != b["t"])
+            assert differ.sum() <= 5                            # ties between coplanar triangles only
+            o = oracle.Scene(moved)
+            o.set_flat_bvh(*sc.flat())
+            for est in (0, 1):                                  # 1: the emitter table has grown from none to 12 triangles
+                tracer.set_option("estimator", est)
+                o.set_estimator(est)
+                if est:
+                    assert all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(sc.emitters(), o.emitters()))
+                    assert len(sc.emitters()[0]) == len(i) // 3
+                for frame in (0, 3):
+                    s.frameID = frame
+                    tracer.trace(sc, s, acc, ldr)
+                    rgb, rays = tracer.last_sample(w * h, rays=True)
+                    r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, frame, 1, nthreads=16)
+                    assert np.array_equal(rays.reshape(h, w), r["rays"]), (width, est, frame)
+                    assert rel_err(rgb.reshape(h, w, 3), r["sample"]).max() < RTOL
+                    tracer.trace(fresh, s, acc, ldr)
+                    rgb2, rays2 = tracer.last_sample(w * h, rays=True)
+                    assert np.array_equal(rays, rays2) and rel_err(rgb, rgb2).max() < RTOL
+            tracer.set_option("estimator", 0)
+    finally:
+        tracer.set_option("estimator", 0)
+        tracer.set_option("count_pixel_rays", 0)
+        tracer.free(acc), tracer.free(ldr)

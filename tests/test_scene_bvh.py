@@ -217,3 +217,85 @@ def test_bvh_cache_roundtrip_and_rejection(ptlib, oracle, tmp_path):
         assert np.array_equal(ne.view(np.uint32), na.view(np.uint32))
     open(path, "wb").write(raw[:100])                            # truncated
     assert not ptlib.Scene(None, data, bvh_cache=path).bvh_was_cached
+
+
+def _moved(ptlib, data, amp, seed=0):
+    """same topology, every vertex displaced by a smooth field + noise; normals left alone"""
+    rng = np.random.default_rng(seed)
+    meshes = []
+    for v, i, m in data.meshes:
+        v2 = v.copy()
+        p = v2["position"].astype(np.float64)
+        p = p + amp * np.stack([np.sin(1.3 * p[:, 1] + 0.2), np.cos(0.9 * p[:, 2]), np.sin(1.1 * p[:, 0])], 1) + rng.uniform(-amp, amp, p.shape) * 0.2
+        v2["position"] = p.astype(np.float32)
+        meshes.append((v2, i, m))
+    return ptlib.SceneData(meshes, data.sky, data.env)
+
+
+@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("width", [2, 4], ids=["bvh2", "q4"])
+@pytest.mark.parametrize("scene", ["default", "soup"])
+def test_refit_keeps_the_tree_and_encloses_the_moved_triangles(ptlib, oracle, builder, width, scene):
+    """mipt_scene_refit (include/mipt.h): the child references stay, the boxes follow the vertices, and traversal of the
+    re-fitted BVH finds what brute force finds on the moved geometry."""
+    data = ptlib.builtin_scene(1) if scene == "default" else soup_scene(6000, 8)
+    sc = ptlib.Scene(None, data, builder=builder, node_width=width)
+    n0, r0 = sc.bvh()
+    moved = _moved(ptlib, data, 0.35)
+    sc.refit(moved)
+    n1, r1 = sc.bvh()
+    assert n1.shape == n0.shape and r1.shape == r0.shape and sc.bvh_width == width
+    assert np.array_equal(n1[:, 12:16].view(np.uint32), n0[:, 12:16].view(np.uint32))            # same tree
+    assert np.array_equal(r1[:, [3, 7]].view(np.uint32), r0[:, [3, 7]].view(np.uint32))          # same reference order
+    assert not np.array_equal(r1[:, 0:3], r0[:, 0:3])
+    o = oracle.Scene(moved)
+    o.set_flat_bvh(n1, r1, width)
+    assert o.check_flat_bvh() == (0, "")
+    og, dg = random_rays(20000, 33)
+    a, st = o.trace_rays(oracle.ISECT_FLAT, og, dg)
+    b, _ = o.trace_rays(oracle.ISECT_BRUTE, og, dg)
+    diff = np.nonzero((a["tri"] != b["tri"]) | (a["t"] != b["t"]))[0]
+    assert len(diff) <= 40 and (ulp_diff(a["t"][diff], b["t"][diff]) <= 4).sum() >= len(diff) - 3
+    # a tree built for the moved geometry is cheaper to traverse, but the re-fitted one is not absurdly worse
+    fresh = ptlib.Scene(None, moved, builder=builder, node_width=width)
+    o.set_flat_bvh(*fresh.flat())
+    _, sf = o.trace_rays(oracle.ISECT_FLAT, og, dg)
+    assert st.node_visits < 6 * sf.node_visits
+    # moving back: the median builder's boxes (no clipped spatial-split leaves) are reproduced exactly in the BVH2 layout
+    sc.refit(data)
+    n2, r2 = sc.bvh()
+    assert np.array_equal(r2, r0)
+    if builder == 1 and width == 2:
+        assert np.array_equal(n2, n0)
+    o2 = oracle.Scene(data)
+    o2.set_flat_bvh(n2, r2, width)
+    assert o2.check_flat_bvh() == (0, "")
+
+
+def test_refit_rejects_another_topology_and_handles_tiny_scenes(ptlib, oracle):
+    data = soup_scene(50, 1)
+    sc = ptlib.Scene(None, data)
+    before = sc.bvh()
+    with pytest.raises(ptlib.MiptError):
+        sc.refit(soup_scene(51, 1))
+    v, i, m = data.meshes[0]
+    with pytest.raises(ptlib.MiptError):
+        sc.refit(ptlib.SceneData([(v, i, m), (v, i, m)], data.sky))
+    bad = i.copy(); bad[5] = len(v)
+    with pytest.raises(ptlib.MiptError):
+        sc.refit(ptlib.SceneData([(v, bad, m)], data.sky))
+    assert all(np.array_equal(a, b) for a, b in zip(before, sc.bvh()))        # failed refits left the scene alone
+    empty = ptlib.Scene(None, ptlib.SceneData([], data.sky))
+    empty.refit(ptlib.SceneData([], data.sky))
+    for width in (2, 4):
+        one = soup_scene(1, 2)
+        s1 = ptlib.Scene(None, one, node_width=width)
+        mv = _moved(ptlib, one, 2.0)
+        s1.refit(mv)
+        o = oracle.Scene(mv)
+        o.set_flat_bvh(*s1.flat())
+        assert o.check_flat_bvh()[0] == 0
+        og, dg = random_rays(3000, 1, -5, 5)
+        f, _ = o.trace_rays(oracle.ISECT_FLAT, og, dg)
+        b, _ = o.trace_rays(oracle.ISECT_BRUTE, og, dg)
+        assert np.array_equal(f["tri"], b["tri"]) and np.array_equal(f["t"], b["t"])
