@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=8)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=32)
+    p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--workload", default="cornell", choices=["cornell", "default", "grid"])
     p.add_argument("--width", type=int, default=0, help="0 = 1920 (cornell, default) or 3840 (grid)")
     p.add_argument("--height", type=int, default=0, help="0 = 1080 (cornell, default) or 2160 (grid)")

@@ -735,7 +735,7 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
             StackArgs SA;
             SA.S = sc->dev; SA.F = A.F; SA.stack = set ? t->wstack2 : t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes;
             // min_descend_lanes auto: 8 for an LDS-resident scene, 24 otherwise (measured optima, profiles/r1/exp_min_descend.log)
-            const bool ldsScene = !sc->dev.wide && sc->dev.nNodes * 4 + sc->dev.nRefs * 3 <= 256 && sc->dev.stackNeed <= 12;   // == kLdsStack, the condition of launch_wavestack
+            const bool ldsScene = wavestack_scene_in_lds(sc->dev);
             SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (ldsScene ? 8 : 24));
             SA.pixCounter = counts; SA.nee = nee ? 1u : 0u;
             SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npix;

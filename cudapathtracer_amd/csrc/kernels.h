@@ -74,6 +74,7 @@ struct DfsArgs {
 
 void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s);
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s);
+bool wavestack_scene_in_lds(const SceneDev& S);    // true: k_wavestack walks this scene from LDS (BVH2, fits the window and the LDS stack)
 void launch_dfs(const DfsArgs& a, int blocks, hipStream_t s);
 void launch_accumulate(const float* sample, float* acc, unsigned char* ldr, float weight, int sumMode,
                        uint32_t pix0, uint32_t npix, hipStream_t s);

@@ -836,8 +836,12 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     MIPT_PROF(if (lane == 0) for (int k = 0; k < 12; k++) atomicAdd(A.stats + 8 + k, pf[k]);)
 }
 
+bool wavestack_scene_in_lds(const SceneDev& S) {
+    return !S.wide && S.nNodes * 4 + S.nRefs * 3 <= kLdsSceneVec && S.stackNeed <= (uint32_t)kLdsStack;
+}
+
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
-    const bool lds = !a.S.wide && a.S.nNodes * 4 + a.S.nRefs * 3 <= kLdsSceneVec && a.S.stackNeed <= (uint32_t)kLdsStack;
+    const bool lds = wavestack_scene_in_lds(a.S);
     if (a.nee) {
         if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
         else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
