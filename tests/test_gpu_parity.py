@@ -202,12 +202,15 @@ def test_tile_size_does_not_change_the_image(tracer, ptlib):
         assert rays == out[0][1] and rel_err(rgb, out[0][0]).max() < RTOL
 
 
-def test_full_size_properties_1080p(tracer, ptlib, oracle):
-    """BASELINE config C2's shape (Cornell 1920x1080, 8 bounces), size-independent properties plus an oracle spot check."""
-    w, h, depth = 1920, 1080, 8
-    data = ptlib.builtin_scene(0)
+@pytest.mark.parametrize("name,w,h,depth", [("cornell", 1920, 1080, 8), ("default", 1920, 1080, 12), ("default", 3840, 2160, 4)],
+                         ids=["C2-cornell-1080p-d8", "C3-default-hdri-1080p-d12", "C4-default-hdri-4k-d4"])
+def test_full_size_properties(tracer, ptlib, oracle, name, w, h, depth):
+    """BASELINE configs C2 / C3 / C4 at their full frame sizes (the default scene under the 2048x1024 synthetic HDRI):
+    size-independent properties plus an oracle spot check on three rows."""
+    data = ptlib.builtin_scene(0) if name == "cornell" else ptlib.builtin_scene(1, ptlib.synthetic_sky())
+    cam_kw = ptlib.CORNELL_CAMERA if name == "cornell" else ptlib.DEFAULT_CAMERA
     sc = ptlib.Scene(tracer, data)
-    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), w, h, depth)
+    s = ptlib.make_settings(ptlib.make_camera(**cam_kw), w, h, depth)
     acc, ldr = dev_buffers(tracer, w, h)
     tracer.set_option("count_pixel_rays", 1)
     try:
@@ -227,7 +230,7 @@ def test_full_size_properties_1080p(tracer, ptlib, oracle):
         o = oracle.Scene(data)
         o.set_flat_bvh(*sc.flat())
         rgb = rgb.reshape(h, w, 3)
-        for y in (0, 517, 1079):
+        for y in (0, h // 2 - 23, h - 1):
             r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 2, 1, rect=(0, y, w, y + 1), nthreads=16)
             assert np.array_equal(rays.reshape(h, w)[y], r["rays"][y])
             assert rel_err(rgb[y], r["sample"][y]).max() < RTOL
