@@ -59,7 +59,7 @@ struct StackArgs {
     Queue stack;                 // waves * cap entries, wave w owns [w*cap, (w+1)*cap)
     uint32_t refill;             // refill idle lanes once this many are idle (1..64)
     uint32_t minDescend;         // a traversal round stops descending when fewer lanes than this are still at inner nodes
-    uint32_t nee;                // 1: env-map importance sampling estimator (occlusion rays), 0: the reference's estimator
+    uint32_t nee;                // option "estimator": 0 the reference's, 1 light sampling (occlusion rays), 2 VNDF + cosine lobes
     uint32_t cap;                // entries per wave
     uint32_t* pixCounter;        // next unclaimed pixel of the frame (reset to 0 before the launch)
     float* sample; uint32_t* pixelRays; unsigned long long* stats;

@@ -243,6 +243,44 @@ MIPT_DEV v3 ggx_rand_dir_inside_cone(Lcg& rng, v3 dir, float size) {
     return sx * dir + sy * up + sz * right;
 }
 
+// ---- estimator 2 (include/mipt.h): the same two lobes sampled the textbook way ------------------------------------
+// diffuse: cosine-weighted hemisphere about N, same basis and draws as rand_dir_inside_cone
+MIPT_DEV v3 cosine_dir_about(Lcg& rng, v3 N) {
+    v3 right, up; cone_basis(N, right, up);
+    float u = rng.NextFloat(), v = rng.NextFloat();
+    float theta = (float)(6.283185307179586 * (double)u);
+    float sn, cs; det_sincosf(theta, &sn, &cs);
+    float r = __builtin_sqrtf(v), cz = __builtin_sqrtf(1 - v);
+    return cz * N + (r * cs) * up + (r * sn) * right;
+}
+// specular: microfacet normal from the GGX distribution of visible normals (Heitz 2018), alpha = roughness
+MIPT_DEV v3 ggx_visible_normal(Lcg& rng, v3 N, v3 d, float alpha) {
+    float u1 = rng.NextFloat(), u2 = rng.NextFloat();
+    if (!(alpha > 0.f)) return N;
+    v3 right, up; cone_basis(N, right, up);
+    v3 V = -d;
+    v3 Ve = mk3(dot3(V, up), dot3(V, right), __builtin_fmaxf(dot3(V, N), 1e-4f));
+    v3 Vh = normalize3(mk3(alpha * Ve.x, alpha * Ve.y, Ve.z));
+    float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    v3 T1 = lensq > 0.f ? mk3(-Vh.y, Vh.x, 0.f) / __builtin_sqrtf(lensq) : mk3(1.f, 0.f, 0.f);
+    v3 T2 = cross3(Vh, T1);
+    float r = __builtin_sqrtf(u1);
+    float phi = (float)(6.283185307179586 * (double)u2);
+    float sn, cs; det_sincosf(phi, &sn, &cs);
+    float t1 = r * cs, t2 = r * sn;
+    float sw = 0.5f * (1 + Vh.z);
+    t2 = (1 - sw) * __builtin_sqrtf(1 - t1 * t1) + sw * t2;
+    float nz = __builtin_sqrtf(__builtin_fmaxf(0.f, 1 - t1 * t1 - t2 * t2));
+    v3 Nh = T1 * t1 + T2 * t2 + Vh * nz;
+    v3 Ne = normalize3(mk3(alpha * Nh.x, alpha * Nh.y, __builtin_fmaxf(1e-6f, Nh.z)));
+    return Ne.x * up + Ne.y * right + Ne.z * N;
+}
+MIPT_DEV float ggx_g1(float nl, float alpha) {
+    if (!(nl > 0.f)) return 0.f;
+    float a2 = alpha * alpha;
+    return (2 * nl) / (nl + __builtin_sqrtf(a2 + (1 - a2) * (nl * nl)));
+}
+
 // ---- miss (OnMiss, CUDATracerProg.cu:796-846) ------------------------------------------------------------------
 MIPT_DEV v3 on_miss(const SceneDev& S, v3 d) {
     if (S.env == nullptr) {
@@ -289,10 +327,11 @@ MIPT_DEV Surface surface_at(const SceneDev& S, v3 o, v3 d, const HitRec& h) {
 // One bounce of LaunchRayRecur (CUDATracerProg.cu:439-528), top-down: given the incoming ray and the hit, produce the
 // two child rays and the factors their radiance is multiplied by.  `rng` supplies GGX (2) then diffuse (2) draws.
 struct Bounce { v3 o1, d1, f1; v3 o2, d2, f2; v3 emit; };
+template <bool PBS = false>      // PBS: estimator 2
 MIPT_DEV Bounce shade_hit(const Material& mat, const Surface& sf, v3 d, bool front, Lcg& rng) {
     Bounce b;
     v3 N = sf.N, P = sf.P;
-    v3 mN = ggx_rand_dir_inside_cone(rng, N, mat.roughness);
+    v3 mN = PBS ? ggx_visible_normal(rng, N, d, mat.roughness) : ggx_rand_dir_inside_cone(rng, N, mat.roughness);
     v3 R = reflect3(d, mN);
     b.o1 = P + N * 1e-6f; b.d1 = R;
     float n1 = 1.f, n2 = mat.n; n2 += FLT_EPSILON;
@@ -306,6 +345,7 @@ MIPT_DEV Bounce shade_hit(const Material& mat, const Surface& sf, v3 d, bool fro
     float rt = 1 - rr;
     v3 absorb = mat.metallic * mat.color + (1 - mat.metallic) * mk3(1.f, 1.f, 1.f);
     b.f1 = absorb * rr;
+    if constexpr (PBS) b.f1 = b.f1 * ggx_g1(dot3(R, N), mat.roughness);
     if (mat.opacity < 1.f) {
         v3 frontv = (d + R) / 2.0f;
         v3 down = d - frontv;
@@ -318,7 +358,7 @@ MIPT_DEV Bounce shade_hit(const Material& mat, const Surface& sf, v3 d, bool fro
         b.d2 = normalize3(front_refr + down * drl);
         b.o2 = P - N * 1e-6f;
     } else {
-        b.d2 = rand_dir_inside_cone(rng, N, 0.49f);
+        b.d2 = PBS ? cosine_dir_about(rng, N) : rand_dir_inside_cone(rng, N, 0.49f);
         b.o2 = P + N * 1e-6f;
     }
     b.f2 = mat.color * rt * ((mat.opacity == 1.f) ? 1.f : (1 - mat.opacity));
@@ -540,7 +580,7 @@ MIPT_DEV uint32_t wave_sum_u32(uint32_t v) { for (int s = 32; s > 0; s >>= 1) v 
 #define MIPT_PROF(x)
 #endif
 
-template <bool LDS_SCENE, bool WIDE, bool NEE>
+template <bool LDS_SCENE, bool WIDE, bool NEE, bool PBS = false>
 __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     constexpr int kSqCap = SqCap<LDS_SCENE>::value;
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
@@ -618,7 +658,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 Material mat = load_material(A.S, sf.mesh);
                 if (!(NEE && (fpix & kNoEmitBit))) add_sample(A.sample, spix, sb * (mat.emissive * mat.emissiveStrength));
                 Lcg rng; rng.state = node_seed(ss0, snode);
-                b = shade_hit(mat, sf, sd, front, rng);
+                b = shade_hit<PBS>(mat, sf, sd, front, rng);
                 b.f1 = sb * b.f1; b.f2 = sb * b.f2;
                 if constexpr (NEE) {
                     // what the diffuse child would find by chance -- the environment when it escapes, the emission of the
@@ -842,7 +882,12 @@ bool wavestack_scene_in_lds(const SceneDev& S) {
 
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
     const bool lds = wavestack_scene_in_lds(a.S);
-    if (a.nee) {
+    if (a.nee == 2u) {      // estimator 2: VNDF specular + cosine diffuse, no occlusion rays
+        if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_wavestack<false, false, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+    }
+    else if (a.nee) {
         if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
         else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
         else hipLaunchKernelGGL((k_wavestack<false, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);

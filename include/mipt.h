@@ -136,6 +136,19 @@ int  mipt_scene_bvh_was_cached(const mipt_scene*);
  *       far less variance under a small bright sun or lamp.  Occlusion rays are counted in mipt_counters.shadow_rays
  *       (and in .rays).  Acts on whichever of env map / emissive triangles the scene has (error if neither); needs
  *       integrator 0 and rng_mode node.
+ *   2 = the same two lobes sampled the textbook way (a different image: the lobes themselves change, not only their
+ *       variance).  Specular: the microfacet normal m is drawn from the GGX distribution of visible normals (Heitz 2018)
+ *       with alpha = roughness, seen from V = -d in the frame (up, right, N) of the reference's cone basis
+ *       (CUDATracerProg.cu:99-104): Ve = (V.up, V.right, max(V.N, 1e-4)); Vh = normalize(alpha Ve.x, alpha Ve.y, Ve.z);
+ *       T1 = (-Vh.y, Vh.x, 0) / |.| (or (1,0,0)), T2 = Vh x T1; r = sqrt(u1), phi = 2 pi u2 (double product as :112),
+ *       t1 = r cos phi, t2 = (1 - s) sqrt(1 - t1^2) + s r sin phi with s = (1 + Vh.z) / 2;
+ *       Nh = t1 T1 + t2 T2 + sqrt(max(0, 1 - t1^2 - t2^2)) Vh; m = normalize(alpha Nh.x, alpha Nh.y, max(1e-6, Nh.z)) back
+ *       in world space; roughness 0 gives m = N exactly (two draws are consumed either way).  The mirror child's weight
+ *       (:463-493, unchanged Fresnel with m) is multiplied by the Smith masking term of the reflected direction,
+ *       G1 = 2 nl / (nl + sqrt(alpha^2 + (1 - alpha^2) nl^2)), nl = R.N, 0 when nl <= 0 (the child is still traced).
+ *       Diffuse: cosine-weighted about N (r = sqrt(v), dir = sqrt(1 - v) N + r cos(theta) up + r sin(theta) right, theta
+ *       = 2 pi u), weight albedo * rt unchanged -- a Lambertian lobe instead of the reference's uniform cap (:518-526).
+ *       Refraction unchanged.  No occlusion rays; needs integrator 0 and rng_mode node.
  * Sampling tables of estimator 1 (rowCdf[envH+1], then envH rows of colCdf[envW+1]); returns the float count,
  * 0 without an env map.  No counterpart in the reference (it has no light sampling). */
 uint64_t mipt_scene_get_env_cdf(const mipt_scene*, float* out, uint64_t cap);

@@ -653,6 +653,46 @@ v3 GGXRandDirInsideCone(Lcg& rng, v3 dir, float size, const MathFns& M) {   // :
     return sx * dir + sy * up + sz * right;
 }
 
+// ---- estimator 2 (specification: include/mipt.h): the same two lobes, sampled the textbook way ------------------
+// diffuse lobe: cosine-weighted hemisphere about N (Malley), same basis and the same two draws as RandDirInsideCone
+v3 CosineDirAbout(Lcg& rng, v3 N, const MathFns& M) {
+    v3 right, up; cone_basis(N, &right, &up);
+    float u = rng.NextFloat(), v = rng.NextFloat();
+    float theta = (float)(M_PI * 2 * u);
+    float sn, cs; M.sincos(theta, &sn, &cs);
+    float r = sqrtf(v), cz = sqrtf(1 - v);
+    return cz * N + (r * cs) * up + (r * sn) * right;
+}
+// specular lobe: microfacet normal from the GGX distribution of visible normals (Heitz 2018), alpha = roughness,
+// seen from V = -d; roughness 0 returns N exactly (as the reference's cone does).  Two draws.
+v3 GgxVisibleNormal(Lcg& rng, v3 N, v3 d, float alpha, const MathFns& M) {
+    float u1 = rng.NextFloat(), u2 = rng.NextFloat();
+    if (!(alpha > 0.f)) return N;
+    v3 right, up; cone_basis(N, &right, &up);
+    v3 V = -d;
+    v3 Ve = mk(dot3(V, up), dot3(V, right), fmaxf(dot3(V, N), 1e-4f));
+    v3 Vh = normalize3(mk(alpha * Ve.x, alpha * Ve.y, Ve.z));
+    float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    v3 T1 = lensq > 0.f ? mk(-Vh.y, Vh.x, 0.f) / sqrtf(lensq) : mk(1.f, 0.f, 0.f);
+    v3 T2 = cross3(Vh, T1);
+    float r = sqrtf(u1);
+    float phi = (float)(M_PI * 2 * u2);
+    float sn, cs; M.sincos(phi, &sn, &cs);
+    float t1 = r * cs, t2 = r * sn;
+    float sw = 0.5f * (1 + Vh.z);
+    t2 = (1 - sw) * sqrtf(1 - t1 * t1) + sw * t2;
+    float nz = sqrtf(fmaxf(0.f, 1 - t1 * t1 - t2 * t2));
+    v3 Nh = T1 * t1 + T2 * t2 + Vh * nz;
+    v3 Ne = normalize3(mk(alpha * Nh.x, alpha * Nh.y, fmaxf(1e-6f, Nh.z)));
+    return Ne.x * up + Ne.y * right + Ne.z * N;
+}
+// Smith masking of the outgoing direction (what VNDF sampling leaves of the BRDF weight besides Fresnel)
+inline float GgxG1(float nl, float alpha) {
+    if (!(nl > 0.f)) return 0.f;
+    float a2 = alpha * alpha;
+    return (2 * nl) / (nl + sqrtf(a2 + (1 - a2) * (nl * nl)));
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Integrator (CUDATracerProg.cu:367-541, 796-846)
 // ------------------------------------------------------------------------------------------------------------
@@ -805,7 +845,8 @@ v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noE
     v3 N = h.front ? hn : -hn;                                  // :442
     Lcg local; Lcg* rng = dfs;
     if (k.rng_mode == ORC_RNG_NODE) { local.state = node_seed(k.s0, node); rng = &local; }
-    v3 mN = GGXRandDirInsideCone(*rng, N, mat.roughness, *k.M);  // :444
+    const bool pbs = k.s->estimator == 2;                        // estimator 2: VNDF specular + cosine diffuse
+    v3 mN = pbs ? GgxVisibleNormal(*rng, N, d, mat.roughness, *k.M) : GGXRandDirInsideCone(*rng, N, mat.roughness, *k.M);  // :444
     v3 R = reflect3(d, mN);                                      // :446
     v3 c = LaunchRayRecur(k, P + N * 1e-6f, R, ttl - 1, dfs, node * 2);      // :448-458
     c = mk(fmaxf(c.x, 0.f), fmaxf(c.y, 0.f), fmaxf(c.z, 0.f));   // :459 clamp to [0,inf)
@@ -821,6 +862,7 @@ v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noE
     v3 col = ld3(mat.color);
     v3 absorb = mat.metallic * col + (1 - mat.metallic) * mk(1.f, 1.f, 1.f);   // :492
     color = absorb * c * rr;                                     // :493
+    if (pbs) color = color * GgxG1(dot3(R, N), mat.roughness);
     v3 o2, d2;
     if (mat.opacity < 1.f) {                                     // :495-516
         v3 front = (d + R) / 2.0f;
@@ -834,7 +876,7 @@ v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noE
         d2 = normalize3(front_refr + down * drl);
         o2 = P - N * 1e-6f;
     } else {                                                     // :518-522
-        d2 = RandDirInsideCone(*rng, N, 0.49f, *k.M);
+        d2 = pbs ? CosineDirAbout(*rng, N, *k.M) : RandDirInsideCone(*rng, N, 0.49f, *k.M);
         o2 = P + N * 1e-6f;
     }
     // estimator 1: what the diffuse child would find by chance -- the environment when it escapes, the emission of the
@@ -985,7 +1027,7 @@ int orc_scene_set_flat_bvh(orc_scene* s, const float* nodes, uint32_t n_nodes, c
     s->fwidth = 2;
     return 0;
 }
-int orc_scene_set_estimator(orc_scene* s, int e) { if (e != 0 && e != 1) return 1; s->estimator = e; return 0; }
+int orc_scene_set_estimator(orc_scene* s, int e) { if (e < 0 || e > 2) return 1; s->estimator = e; return 0; }
 uint64_t orc_scene_get_env_cdf(const orc_scene* s, float* out, uint64_t cap) {
     if (out && cap >= s->envCdf.size()) memcpy(out, s->envCdf.data(), s->envCdf.size() * sizeof(float));
     return s->envCdf.size();

@@ -187,3 +187,74 @@ def test_emitter_sampling_keeps_the_expectation_on_the_cornell_box(ptlib, oracle
     assert abs(imgs[1].mean() / imgs[0].mean() - 1) < 0.03
     blocks = [im.reshape(2, 16, 3, 16, 3).mean((1, 3)) for im in imgs]
     assert np.abs(blocks[1] / blocks[0] - 1).mean() < 0.08
+
+
+def _plane_under_sky(ptlib, material, env):
+    v = np.zeros(4, ptlib.VERTEX_DTYPE)
+    v["position"] = [(-50, 0, -50), (-50, 0, 50), (50, 0, 50), (50, 0, -50)]          # MakeQuad's order: front face up
+    v["normal"] = (0, 1, 0)
+    return ptlib.SceneData([(v, np.array([0, 1, 2, 0, 2, 3], np.uint32), material)], ptlib.SkyLight(), env)
+
+
+def _looking_down(ptlib, w=16, h=16, depth=2, zenith=np.pi, fov=0.1):
+    cam = ptlib.make_camera(pos=(0.0, 5.0, 0.0), azimuth=0.0, zenith=float(np.float32(zenith)), fov=fov)
+    return ptlib.make_settings(cam, w, h, depth)
+
+
+def test_estimator_2_diffuse_lobe_is_cosine_weighted(ptlib, oracle):
+    """include/mipt.h, estimator 2: under a sky of radiance max(cos zenith, 0) a white diffuse plane seen head-on shows
+    E[cos] of its diffuse lobe: 2/3 for the cosine-weighted lobe, (1 + 0.02) / 2 for the reference's uniform cap."""
+    H, W = 64, 128
+    env = np.zeros((H, W, 3), np.float32)
+    env[...] = np.maximum(np.cos((np.arange(H) + 0.5) / H * np.pi), 0)[:, None, None]
+    data = _plane_under_sky(ptlib, ptlib.make_material(color=(1, 1, 1), roughness=0.0, metallic=0.0, n=1.0), env)
+    o = oracle.Scene(data)
+    o.set_flat_bvh(*ptlib.Scene(None, data).flat())
+    s = _looking_down(ptlib)
+    means = []
+    for est in (0, 2):
+        o.set_estimator(est)
+        r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, 64, want_ldr=False)
+        assert (r["rays"] == 3).all() and r["stats"].shadow_rays == 0
+        means.append(float(r["acc"][..., :3].mean()))
+    assert abs(means[0] - 0.51) < 0.01 and abs(means[1] - 2 / 3) < 0.01, means
+
+
+def test_estimator_2_specular_lobe_is_ggx(ptlib, oracle):
+    """A white metal under a uniform sky shows E[G1(R.N)] over the sampled microfacet normals.  Head-on the VNDF is the
+    GGX distribution itself (tan^2 theta_m = alpha^2 u / (1 - u)), so the expectation is a one-dimensional integral."""
+    env = np.ones((8, 16, 3), np.float32)
+    s = _looking_down(ptlib)
+    for alpha in (0.0, 0.3, 0.7):
+        data = _plane_under_sky(ptlib, ptlib.make_material(color=(1, 1, 1), roughness=alpha, metallic=1.0), env)
+        o = oracle.Scene(data)
+        o.set_flat_bvh(*ptlib.Scene(None, data).flat())
+        o.set_estimator(2)
+        r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, 64, want_ldr=False)
+        got = float(r["acc"][..., :3].mean())
+        u = (np.arange(200000) + 0.5) / 200000
+        t2 = alpha * alpha * u / (1 - u)
+        nl = (1 - t2) / (1 + t2)                                        # cos(2 theta_m)
+        a2 = alpha * alpha
+        g1 = np.where(nl > 0, 2 * nl / (nl + np.sqrt(a2 + (1 - a2) * nl * nl)), 0.0)
+        assert abs(got - g1.mean()) < 0.01, (alpha, got, g1.mean())
+        if alpha == 0.0:
+            assert got == 1.0
+    # oblique view (alpha 0.7): sampling visible normals and weighting by G1(l) must integrate to the directional albedo
+    # of the GGX BRDF D G1(v) G1(l) / (4 n.v n.l) -- computed here by plain quadrature over outgoing directions
+    zen = 2.3
+    so = _looking_down(ptlib, zenith=zen, fov=0.05)
+    r = o.render(so, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, 128, want_ldr=False)
+    V = np.array([-np.sin(zen), -np.cos(zen), 0.0])
+    ct = (np.arange(600) + 0.5) / 600
+    phi = (np.arange(1200) + 0.5) / 1200 * 2 * np.pi
+    CT, PH = np.meshgrid(ct, phi, indexing="ij")
+    ST = np.sqrt(1 - CT ** 2)
+    Hv = np.stack([ST * np.cos(PH), CT, ST * np.sin(PH)], -1) + V
+    nh = Hv[..., 1] / np.linalg.norm(Hv, axis=-1)
+    D = a2 / (np.pi * (nh ** 2 * (a2 - 1) + 1) ** 2)
+    G1 = lambda c: 2 * c / (c + np.sqrt(a2 + (1 - a2) * c * c))
+    albedo = float((D * G1(V[1]) * G1(CT) / (4 * V[1] * CT) * CT).mean() * 2 * np.pi)
+    assert 0.5 < albedo < 0.6 and abs(float(r["acc"][..., :3].mean()) - albedo) < 0.012, albedo
+    with pytest.raises(ValueError):
+        o.set_estimator(3)
