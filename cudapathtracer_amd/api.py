@@ -86,6 +86,7 @@ lib.mipt_scene_create.argtypes = [_vp, C.POINTER(SceneDesc), C.POINTER(_vp)]
 lib.mipt_scene_destroy.argtypes = [_vp]
 lib.mipt_scene_destroy.restype = None
 lib.mipt_scene_refit.argtypes = [_vp, _vp]
+lib.mipt_set_tile_partition.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32]
 lib.mipt_scene_get_bvh.argtypes = [_vp, _vp, C.POINTER(C.c_uint32), _vp, C.POINTER(C.c_uint32)]
 lib.mipt_scene_triangle_count.argtypes = [_vp]
 lib.mipt_scene_triangle_count.restype = C.c_uint32
@@ -342,6 +343,10 @@ class Tracer:
 
     def set_option(self, key, value):
         self._chk(lib.mipt_set_option(self.h, key.encode(), int(value)), f"set_option {key}")
+
+    def set_tile_partition(self, tile_rows, n_parts, part):
+        """Render only the row tiles part, part + n_parts, ... (tiles of tile_rows rows); n_parts = 1: the whole frame."""
+        self._chk(lib.mipt_set_tile_partition(self.h, tile_rows, n_parts, part), "set_tile_partition")
 
     def set_stream(self, stream_ptr):
         self._chk(lib.mipt_set_stream(self.h, stream_ptr), "set_stream")

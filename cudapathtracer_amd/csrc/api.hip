@@ -36,6 +36,7 @@ struct mipt_tracer {
     int64_t estimator = 0;
     int64_t profileLevels = 0;
     int64_t integrator = 0;          // 0 persistent wave stacks, 1 level-synchronous queues
+    uint32_t tileRows = 0, tileParts = 1, tilePart = 0;     // mipt_set_tile_partition (tileParts 1: the whole frame)
     int64_t pipelineFrames = 1;      // consecutive frames alternate between two streams / buffer sets (see mipt_render)
     // work buffers
     Queue wstack = {}; size_t wstackEntries = 0;
@@ -409,6 +410,13 @@ int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
     return MIPT_OK;
 }
 
+int mipt_set_tile_partition(mipt_tracer* t, uint32_t tile_rows, uint32_t n_parts, uint32_t part) {
+    if (!t) return MIPT_E_INVALID;
+    if (n_parts == 0 || part >= n_parts || (n_parts > 1 && tile_rows == 0)) return fail(t, MIPT_E_INVALID, "tile partition: need tile_rows >= 1 and part < n_parts");
+    t->tileRows = tile_rows; t->tileParts = n_parts; t->tilePart = part;
+    return MIPT_OK;
+}
+
 int mipt_get_counters(mipt_tracer* t, mipt_counters* out) {
     if (!t || !out) return MIPT_E_INVALID;
     int rc = mipt_synchronize(t); if (rc) return rc;
@@ -646,6 +654,19 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
     // and no integrator launch ever queues behind a fold.
     // Off for a caller-supplied stream (the caller expects everything in order there), per-pixel ray counting, and
     // the other integrators.
+    // row-tile partition: this handle renders tiles part, part + parts, ... of tile_rows rows each
+    Band band{ 0u, 1u, 0u };
+    uint32_t npixPart = npix;
+    if (t->tileParts > 1) {
+        if (t->rngMode != MIPT_RNG_NODE || t->integrator != 0 || D < 1) return fail(t, MIPT_E_INVALID, "a tile partition needs integrator 0, rng_mode node and maxDepth >= 1");
+        const uint32_t W = st->viewportWidth, H = st->viewportHeight;
+        if ((uint64_t)t->tileRows * W >= (1ull << 31)) return fail(t, MIPT_E_LIMIT, "tile too large");
+        const uint32_t nTiles = (H + t->tileRows - 1) / t->tileRows;
+        uint64_t rows = 0;
+        for (uint32_t k = t->tilePart; k < nTiles; k += t->tileParts) rows += std::min(t->tileRows, H - k * t->tileRows);
+        band = Band{ t->tileRows * W, t->tileParts, t->tilePart };
+        npixPart = (uint32_t)(rows * W);
+    }
     const bool pipe = t->pipelineFrames && t->stream == t->own && !t->countPixelRays && t->rngMode == MIPT_RNG_NODE && t->integrator == 0 && D >= 1;
     if (!pipe) join_aux(t);
     if (t->rngMode == MIPT_RNG_DFS) {
@@ -739,11 +760,11 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
             const bool ldsScene = wavestack_scene_in_lds(sc->dev);
             SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (ldsScene ? 8 : 24));
             SA.pixCounter = counts; SA.nee = (uint32_t)t->estimator;
-            SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npix;
+            SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npixPart; SA.band = band;
             mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
             if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, S)); }
             HIPCHK(t, hipEventRecord(ka, S));
-            launch_wavestack(SA, std::min<int>((int)((npix + 255) / 256), persistentBlocks), S);
+            if (npixPart) launch_wavestack(SA, std::min<int>((int)((npixPart + 255) / 256), persistentBlocks), S);
             HIPCHK(t, hipEventRecord(kb, S));
             if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, S)); t->levelPending.push_back(le); }
             t->launches++;
@@ -774,7 +795,7 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
         const float weight = (float)(1.0 / (frame + 1.0));       // CUDATracerProg.cu:878
         mipt_tracer::LevelEv ae{ nullptr, nullptr, -1 };
         if (t->profileLevels) { HIPCHK(t, hipEventCreate(&ae.a)); HIPCHK(t, hipEventCreate(&ae.b)); HIPCHK(t, hipEventRecord(ae.a, F)); }
-        launch_accumulate(sample, acc_dev, ldr_dev, weight, sum_mode, 0, npix, F);
+        launch_accumulate(sample, acc_dev, ldr_dev, weight, sum_mode, band, 0, npixPart, F);
         if (t->profileLevels) { HIPCHK(t, hipEventRecord(ae.b, F)); t->levelPending.push_back(ae); }
         if (pipe) { HIPCHK(t, hipEventRecord(t->foldEv[slot], F)); t->foldValid[slot] = true; }
         t->frames++;

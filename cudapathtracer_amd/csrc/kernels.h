@@ -54,6 +54,11 @@ struct LevelArgs {
 
 // Persistent wave-private work stacks (the default integrator): every wave owns `cap` ray slots of the three SoA
 // arrays and runs its rays' whole recursion trees out of that LIFO, refilling idle lanes with fresh primary rays.
+// Row-tile partition of the frame (mipt_set_tile_partition): tile k = `pixels` consecutive pixels (whole rows); this
+// handle renders tiles first, first + stride, ...  pixels == 0: the whole frame.  Local pixel index L of the partition
+// maps to frame pixel ((L / pixels) * stride + first) * pixels + L % pixels.
+struct Band { uint32_t pixels, stride, first; };
+
 struct StackArgs {
     SceneDev S; FrameDev F;
     Queue stack;                 // waves * cap entries, wave w owns [w*cap, (w+1)*cap)
@@ -63,7 +68,8 @@ struct StackArgs {
     uint32_t cap;                // entries per wave
     uint32_t* pixCounter;        // next unclaimed pixel of the frame (reset to 0 before the launch)
     float* sample; uint32_t* pixelRays; unsigned long long* stats;
-    uint32_t pix0, npix;
+    uint32_t pix0, npix;         // npix: pixels of this handle's partition (the whole frame without one)
+    Band band;
 };
 
 struct DfsArgs {
@@ -76,7 +82,7 @@ void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s);
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s);
 bool wavestack_scene_in_lds(const SceneDev& S);    // true: k_wavestack walks this scene from LDS (BVH2, fits the window and the LDS stack)
 void launch_dfs(const DfsArgs& a, int blocks, hipStream_t s);
-void launch_accumulate(const float* sample, float* acc, unsigned char* ldr, float weight, int sumMode,
+void launch_accumulate(const float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, Band band,
                        uint32_t pix0, uint32_t npix, hipStream_t s);
 void launch_tonemap(const float* acc, float scale, uint32_t npix, unsigned char* ldr, hipStream_t s);
 void launch_trace_rays(const SceneDev& S, const float* o, const float* d, uint32_t n, void* hits, hipStream_t s);

@@ -505,6 +505,7 @@ void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s) {
 // =================================================================================================================
 // shade-queue entries per wave (a terminated ray that finds it full parks one round later); sized so that a
 // 256-thread block uses exactly a quarter of the CU's 160 KiB: 4 x cap x 64 B + 12 KiB traversal stacks (+ 4 KiB scene); 12 stack entries / cap 112 measured better than 8 / 128 and 16 / 96
+MIPT_DEV uint32_t band_pixel(const Band& b, uint32_t local) { return ((local / b.pixels) * b.stride + b.first) * b.pixels + local % b.pixels; }
 template <bool LDS_SCENE> struct SqCap { static constexpr int value = LDS_SCENE ? 96 : 112; };
 constexpr int kSqWords = 16;         // dwords per entry, SoA by dword: conflict-free LDS access
 
@@ -753,6 +754,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 if (rank < got + take) {
                     if (rank < got) {
                         pix = A.pix0 + pbase + rank; node = 1; beta = mk3(1.f, 1.f, 1.f);
+                        if (A.band.pixels) pix = band_pixel(A.band, pix);
                         gen_primary(A.F, pix, o, d, s0);
                     } else {
                         const uint32_t e = sp + (rank - got);
@@ -1017,10 +1019,11 @@ MIPT_DEV unsigned char tonemap1(float x) {
     return (unsigned char)(int)(x * 255);
 }
 __global__ void __launch_bounds__(kBlock) k_accumulate(const float4* sample, float4* acc, uchar4* ldr, float weight, int sumMode,
-                                                        uint32_t pix0, uint32_t npix) {
+                                                        Band band, uint32_t pix0, uint32_t npix) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= npix) return;
     uint32_t p = pix0 + i;
+    if (band.pixels) p = band_pixel(band, p);
     float4 c = sample[p], a = acc[p];
     float r, g, b;
     if (sumMode) { r = a.x + c.x; g = a.y + c.y; b = a.z + c.z; }
@@ -1028,10 +1031,10 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4* sample, flo
     acc[p] = make_float4(r, g, b, 1.f);
     if (ldr) ldr[p] = make_uchar4(tonemap1(r), tonemap1(g), tonemap1(b), 255);
 }
-void launch_accumulate(const float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, uint32_t pix0, uint32_t npix, hipStream_t s) {
+void launch_accumulate(const float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, Band band, uint32_t pix0, uint32_t npix, hipStream_t s) {
     if (!npix) return;
     hipLaunchKernelGGL(k_accumulate, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const float4*)sample, (float4*)acc, (uchar4*)ldr,
-                       weight, sumMode, pix0, npix);
+                       weight, sumMode, band, pix0, npix);
 }
 __global__ void __launch_bounds__(kBlock) k_tonemap(const float4* acc, float scale, uint32_t npix, uchar4* ldr) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;

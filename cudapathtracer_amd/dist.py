@@ -4,7 +4,31 @@ The reference is single-GPU.  Samples are independent given the (pixel, frameID)
 so the path shards with no data-path collective: the scene is replicated, rank r of G renders frame indices
 r, r+G, r+2G, ... into a private SUM buffer, and one RCCL reduce (sum, fp32) of the accumulation buffers combines
 them at the end; the root scales by 1/N and tonemaps.  One process per GPU (torch.distributed, backend nccl = RCCL).
+
+Alternative ("interleaved row tiles" for interactive latency): every rank renders EVERY frame but only its
+share of the image -- tiles of `tile_rows` rows dealt round-robin (`mipt_set_tile_partition`) -- so a frame is
+finished G times sooner; the buffers hold zeros outside a rank's tiles and the same reduce(SUM) assembles the image.
 """
+
+
+def tiles_for_rank(height, tile_rows, rank, world):
+    """Row ranges [(y0, y1), ...] rank `rank` of `world` renders: tiles rank, rank + world, ... of tile_rows rows."""
+    if world < 1 or not 0 <= rank < world or tile_rows < 1:
+        raise ValueError("bad rank/world/tile_rows")
+    n_tiles = (height + tile_rows - 1) // tile_rows
+    return [(k * tile_rows, min((k + 1) * tile_rows, height)) for k in range(rank, n_tiles, world)]
+
+
+def assemble_tiles(acc, dst=0, group=None):
+    """Tile-partitioned ranks hold the running MEAN in their own tiles and zeros elsewhere: one reduce(SUM) assembles the
+    image on `dst` (alpha forced to 1).  Returns it on dst, None elsewhere."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_rank(group) != dst:
+            return None
+    acc[..., 3] = 1.0
+    return acc
 
 
 def frames_for_rank(first_frame, n_frames, rank, world):

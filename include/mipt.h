@@ -95,6 +95,13 @@ const char* mipt_last_error(const mipt_tracer*);           /* replaces CUDA_CHEC
 int  mipt_set_stream(mipt_tracer*, void* hip_stream);      /* NULL = the tracer's own stream */
 int  mipt_synchronize(mipt_tracer*);
 int  mipt_set_option(mipt_tracer*, const char* key, int64_t value);   /* "tile_pixels", "rng_mode", "block" ... */
+/* Image-tile partition (SURVEY 8e's alternative to sample striding; the reference is single-GPU and has neither): the
+ * frame is cut into tiles of `tile_rows` whole rows, tile k = rows [k * tile_rows, (k+1) * tile_rows); from now on
+ * mipt_render / mipt_trace on this handle render and fold only the tiles part, part + n_parts, part + 2 n_parts, ...
+ * and leave every other pixel of the caller's buffers untouched.  n_parts = 1 restores the whole frame.  A pixel's
+ * sample does not depend on the partition (seeding is per pixel and frame, CUDATracerProg.cu:373-377).  Needs
+ * integrator 0 and rng_mode node. */
+int  mipt_set_tile_partition(mipt_tracer*, uint32_t tile_rows, uint32_t n_parts, uint32_t part);
 int  mipt_get_counters(mipt_tracer*, mipt_counters* out);
 int  mipt_reset_counters(mipt_tracer*);
 int  mipt_get_level_profile(mipt_tracer*, mipt_level_profile* out);

@@ -119,3 +119,55 @@ def test_progressive_preview_reduce(tmp_path, world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-3000:]
     assert open(out).read() == "ok"
+
+
+def test_tiles_for_rank_partition():
+    from cudapathtracer_amd.dist import tiles_for_rank
+    for height, tile_rows, world in ((1080, 16, 8), (2160, 64, 3), (7, 3, 2), (5, 8, 4), (1, 1, 1)):
+        rows = np.zeros(height, int)
+        for r in range(world):
+            for y0, y1 in tiles_for_rank(height, tile_rows, r, world):
+                assert 0 <= y0 < y1 <= height and y0 % tile_rows == 0 and (y0 // tile_rows) % world == r
+                rows[y0:y1] += 1
+        assert (rows == 1).all()                                  # every row belongs to exactly one rank
+    with pytest.raises(ValueError):
+        tiles_for_rank(10, 0, 0, 1)
+
+
+TILE_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+from cudapathtracer_amd.dist import tiles_for_rank, assemble_tiles
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+H, W, T = 23, 6, 4
+acc = torch.zeros((H, W, 4))
+for frame in range(5):                     # stand-in for tracer.trace with a tile partition: running mean in own tiles only
+    w = 1.0 / (frame + 1)
+    for y0, y1 in tiles_for_rank(H, T, rank, world):
+        ys = torch.arange(y0, y1, dtype=torch.float32)[:, None, None]
+        acc[y0:y1, :, :3] = acc[y0:y1, :, :3] * (1 - w) + (ys + frame) * w
+        acc[y0:y1, :, 3] = 1.0
+img = assemble_tiles(acc)
+if rank == 0:
+    want = torch.arange(H, dtype=torch.float32)[:, None, None] + 2.0       # mean of y + frame over frames 0..4
+    assert torch.allclose(img[..., :3], want.expand(H, W, 3)) and (img[..., 3] == 1).all()
+    open(os.environ["OUT"], "w").write("ok")
+else:
+    assert img is None
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_tile_partition_assembles_by_reduce(tmp_path, world):
+    out = str(tmp_path / "ok.txt")
+    script = tmp_path / "worker.py"
+    script.write_text(TILE_WORKER)
+    env = dict(os.environ, REPO=ROOT, OUT=out, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(out).read() == "ok"

@@ -618,3 +618,68 @@ def test_estimator_2_matches_oracle(tracer, ptlib, oracle, name, width):
         tracer.set_option("estimator", 0)
         tracer.set_option("count_pixel_rays", 0)
         tracer.free(acc), tracer.free(ldr)
+
+
+def test_tile_partition_renders_each_pixel_as_the_full_frame_does(tracer, ptlib):
+    """mipt_set_tile_partition: the parts together are the frame (same ray tree per pixel, radiance to the usual
+    tolerance), each part leaves the other parts' pixels alone, and the running mean continues inside the tiles."""
+    from cudapathtracer_amd.dist import tiles_for_rank
+    data = MG.scene_data("default")
+    sc = ptlib.Scene(tracer, data)
+    w, h, depth, T, G = 120, 77, 6, 8, 3            # 10 tiles, the last one 5 rows
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.DEFAULT_CAMERA), w, h, depth)
+    acc, ldr = dev_buffers(tracer, w, h)
+    acc2, ldr2 = dev_buffers(tracer, w, h)
+    tracer.set_option("count_pixel_rays", 1)
+    try:
+        for frame in (0, 1, 2):
+            s.frameID = frame
+            tracer.trace(sc, s, acc, ldr)
+        full, full_ldr = tracer.download(acc, (h, w, 4), np.float32), tracer.download(ldr, (h, w, 4), np.uint8)
+        _, full_rays = tracer.last_sample(w * h, rays=True)
+        total = 0
+        for part in range(G):
+            tracer.set_tile_partition(T, G, part)
+            mine = np.zeros(h, bool)
+            for y0, y1 in tiles_for_rank(h, T, part, G):
+                mine[y0:y1] = True
+            before = tracer.download(acc2, (h, w, 4), np.float32)
+            for frame in (0, 1, 2):
+                s.frameID = frame
+                tracer.reset_counters()
+                tracer.trace(sc, s, acc2, ldr2)
+            _, rays = tracer.last_sample(w * h, rays=True)
+            rays = rays.reshape(h, w)
+            assert np.array_equal(rays[mine], full_rays.reshape(h, w)[mine]) and (rays[~mine] == 0).all()
+            assert tracer.counters().rays == int(rays.sum(dtype=np.uint64))
+            total += int(mine.sum())
+            after = tracer.download(acc2, (h, w, 4), np.float32)
+            later = np.zeros(h, bool)
+            for q in range(part + 1, G):
+                for y0, y1 in tiles_for_rank(h, T, q, G):
+                    later[y0:y1] = True
+            assert np.array_equal(after[later], before[later]) and (after[later] == 0).all()      # not its tiles: untouched
+        assert total == h
+        got, got_ldr = tracer.download(acc2, (h, w, 4), np.float32), tracer.download(ldr2, (h, w, 4), np.uint8)
+        assert rel_err(got, full).max() < RTOL and np.abs(got_ldr.astype(int) - full_ldr.astype(int)).max() <= 1
+        # pipelined frames (no per-pixel counter) give the same, and the other integrators refuse a partition
+        tracer.set_option("count_pixel_rays", 0)
+        tracer.memset(acc2, 0, w * h * 16)
+        for part in range(G):
+            tracer.set_tile_partition(T, G, part)
+            tracer.render(sc, s, 0, 3, acc2, ldr2)
+        assert rel_err(tracer.download(acc2, (h, w, 4), np.float32), full).max() < RTOL
+        tracer.set_option("integrator", 1)
+        with pytest.raises(ptlib.MiptError):
+            tracer.trace(sc, s, acc2, ldr2)
+        tracer.set_option("integrator", 0)
+        with pytest.raises(ptlib.MiptError):
+            tracer.set_tile_partition(0, 2, 0)
+        with pytest.raises(ptlib.MiptError):
+            tracer.set_tile_partition(8, 2, 2)
+    finally:
+        tracer.set_tile_partition(0, 1, 0)
+        tracer.set_option("integrator", 0)
+        tracer.set_option("count_pixel_rays", 0)
+        for b in (acc, ldr, acc2, ldr2):
+            tracer.free(b)
