@@ -285,7 +285,7 @@ def main():
                        "triangles": data.triangle_count, "bvh": "sbvh" + ("-q4" if sc.bvh_width == 4 else ""), "rng": "node", "integrator": "wave-stacks" if a.integrator == 0 else "level-queues", "parallelism": f"sample-striding x{world}",
                        "env_map": None if data.env is None else "synthetic 2048x1024"},
             "spp_per_s": round(a.steps * world / dt, 3), "rays_per_step_per_gpu": round(total_rays / a.steps / world, 1),
-            "shadow_rays": round(total_shadow / a.steps / world, 1), "estimator": "reference" if a.estimator == 0 else "light sampling (env map + emissive triangles)", "kernel_ms_per_step": round(cnt.kernel_ms / a.steps, 3),
+            "shadow_rays": round(total_shadow / a.steps / world, 1), "estimator": ("reference", "light sampling (env map + emissive triangles)", "VNDF specular + cosine diffuse lobes")[a.estimator], "kernel_ms_per_step": round(cnt.kernel_ms / a.steps, 3),
             "level_ms": [round(prof.ms[k] / a.steps, 3) for k in range(depth)] if a.integrator else None,
             "level_mrays": [round(prof.rays[k] / a.steps / 1e6, 2) for k in range(depth)] if a.integrator else None,
             "accumulate_ms": round(prof.accumulate_ms / a.steps, 3),
