@@ -29,6 +29,15 @@ for w in "${WL[@]}"; do
   timeout -k 10 400 python3 $R/bench.py --workload $w --steps $steps --warmup 2 > $OUT/bench_$w.json 2> $OUT/bench_$w.err || { echo "bench failed for $w"; exit 1; }
   tail -c 2500 $OUT/bench_$w.json
 done
+# the same without the frame pipeline: one launch at a time, so HIP-event windows and rocprofv3 durations are those of
+# the kernel alone and must agree
+for w in "${WL[@]}"; do
+  steps=8; [ $w = grid ] && steps=4
+  echo "== $w: serial launches (--pipeline 0)"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kts_$w -o kt -- python3 $R/bench.py --workload $w --steps $steps --warmup 2 --cpu-seconds 0 --pipeline 0 > $OUT/kts_$w.log 2>&1 || { echo "serial kernel trace failed for $w"; exit 1; }
+  cp $(find $OUT/kts_$w -name '*kernel_stats.csv' | head -1) $OUT/${w}_serial_kernel_stats.csv
+  timeout -k 10 400 python3 $R/bench.py --workload $w --steps $steps --warmup 2 --pipeline 0 > $OUT/bench_${w}_serial.json 2> $OUT/bench_${w}_serial.err || { echo "serial bench failed for $w"; exit 1; }
+done
 if [ -f $R/cudapathtracer_amd/libmipt_prof.so ]; then
   for w in "${WL[@]}"; do
     echo "== $w: lane profile (instrumented build)"
