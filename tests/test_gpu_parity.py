@@ -202,13 +202,14 @@ def test_tile_size_does_not_change_the_image(tracer, ptlib):
         assert rays == out[0][1] and rel_err(rgb, out[0][0]).max() < RTOL
 
 
-@pytest.mark.parametrize("name,w,h,depth", [("cornell", 1920, 1080, 8), ("default", 1920, 1080, 12), ("default", 3840, 2160, 4), ("grid", 3840, 2160, 4)],
-                         ids=["C2-cornell-1080p-d8", "C3-default-hdri-1080p-d12", "C4-default-hdri-4k-d4", "C5-grid-1Mtri-4k-d4"])
+@pytest.mark.parametrize("name,w,h,depth", [("cornell", 1920, 1080, 8), ("default", 1920, 1080, 12), ("default", 3840, 2160, 4), ("grid", 3840, 2160, 4),
+                                            ("grid10m", 3840, 2160, 4)],
+                         ids=["C2-cornell-1080p-d8", "C3-default-hdri-1080p-d12", "C4-default-hdri-4k-d4", "C5-grid-1Mtri-4k-d4", "C5-grid-10Mtri-4k-d4"])
 def test_full_size_properties(tracer, ptlib, oracle, name, w, h, depth):
     """BASELINE configs C2 / C3 / C4 / C5 at their full frame sizes (the default scene under the 2048x1024 synthetic HDRI):
     size-independent properties plus an oracle spot check on three rows."""
-    if name == "grid":      # bench.py's C5 stand-in at a tenth of its triangle count (708^2 quads = 1.0 M triangles)
-        v, i = ptlib.grid_mesh(708, 8.0, 1.0, 1)
+    if name.startswith("grid"):      # bench.py's C5 stand-in: 2236^2 quads = 10.0 M triangles, and a tenth of it (708^2)
+        v, i = ptlib.grid_mesh(2236 if name == "grid10m" else 708, 8.0, 1.0, 1)
         data = ptlib.SceneData([(v, i, ptlib.make_material(color=(0.8, 0.8, 0.8)))], ptlib.SkyLight(), ptlib.synthetic_sky())
         cam_kw = dict(pos=(-7.0, 4.0, 0.0), azimuth=0.0, zenith=2.0, fov=float(np.float32(np.pi / 3)))
     else:
