@@ -120,16 +120,27 @@ def main():
     import torch
     import torch.distributed as dist
     local = local % max(torch.cuda.device_count(), 1)      # rehearsals may put several ranks on one GPU
-    if world > 1:
-        torch.cuda.set_device(local)
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group("gloo")
+    # BENCH_FORCE_COLLECTIVES=1: run the N > 1 flow (process group, warm-up reduce, sum buffers, reduce, all_reduce) with
+    # whatever world size there is -- a one-rank rehearsal of the RCCL calls on a one-GPU box
+    multi = world > 1 or bool(os.environ.get("BENCH_FORCE_COLLECTIVES"))
     if a.gpus != world and rank == 0:
         print(f"note: --gpus {a.gpus} but WORLD_SIZE {world}; using {world} process(es)", file=sys.stderr)
+    # order matters twice: torch initialises the GPU before libmipt is loaded (two HIP clients in one process), and the
+    # tracer takes its hardware queues (mipt_create) before RCCL creates its streams -- a process has only
+    # GPU_MAX_HW_QUEUES of them and the frame pipeline needs two that are not shared
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.zeros(1, device=dev)
     import cudapathtracer_amd as pt
     from cudapathtracer_amd import dist as ptdist
+    t = pt.Tracer(local)
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     depth = a.depth or {"cornell": 8, "default": 12, "grid": 4}[a.workload]
     W = a.width or (3840 if a.workload == "grid" else 1920)
@@ -150,15 +161,12 @@ def main():
     settings = pt.make_settings(cam, W, H, depth)
 
     dbg("scene data ready")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    t = pt.Tracer(local)
     if a.tile_pixels:
         t.set_option("tile_pixels", a.tile_pixels)
     t.set_option("integrator", a.integrator)
     t.set_option("estimator", a.estimator)
     t.set_option("pipeline_frames", a.pipeline)
-    if a.workload == "grid" and world > 1:
+    if a.workload == "grid" and multi:
         # 10 M triangles: rank 0 builds the BVH and writes the cache file, the others load it instead of building eight times
         cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mipt_bench_grid{a.grid_n}_w{a.node_width}.bvh")
         sc = pt.Scene(t, data, node_width=a.node_width, bvh_cache=cache) if rank == 0 else None
@@ -171,7 +179,7 @@ def main():
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     ldr = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    sum_mode = 1 if world > 1 else 0
+    sum_mode = 1 if multi else 0
 
     def step(i):   # global step index -> this rank's frame
         frame = i * world + rank
@@ -180,17 +188,22 @@ def main():
     def barrier():
         t.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
 
     for i in range(a.warmup):
         step(i)
     dbg("warm-up frames queued")
-    if world > 1:   # warm the RCCL path too, then start the timed run from a clean sum buffer
+    if multi:   # warm the RCCL path too, then start the timed run from a clean sum buffer
         t.synchronize()
         dbg("warm-up frames done")
-        warm = acc.clone() if a.backend == "nccl" else acc.cpu()
-        dist.reduce(warm, dst=0, op=dist.ReduceOp.SUM)
+        # the whole closing sequence once, untimed: reduce, scale, tonemap (first use of a torch kernel or an RCCL
+        # communicator costs tens of milliseconds)
+        warm = ptdist.reduce_accumulation(acc.clone() if a.backend == "nccl" else acc.cpu(), max(a.warmup, 1) * world, dst=0)
+        if rank == 0:
+            warm = warm.to(dev)
+            torch.cuda.synchronize()
+            t.tonemap(warm.data_ptr(), 1.0, W * H, ldr.data_ptr())
         dbg("warm-up reduce done")
         acc.zero_()
     dbg("warm-up done")
@@ -202,7 +215,8 @@ def main():
     for i in range(a.steps):
         step(a.warmup + i)
     t.synchronize()
-    if world > 1:   # the path's one exchange step: reduce the sum buffers onto rank 0, scale, tonemap
+    t_frames = time.perf_counter() - t0
+    if multi:   # the path's one exchange step: reduce the sum buffers onto rank 0, scale, tonemap
         mean = ptdist.reduce_accumulation(acc if a.backend == "nccl" else acc.cpu(), a.steps * world, dst=0)
         if rank == 0:
             mean = mean.to(dev)
@@ -210,7 +224,7 @@ def main():
             t.tonemap(mean.data_ptr(), 1.0, W * H, ldr.data_ptr())
     barrier()
     dt = time.perf_counter() - t0
-    dbg("timed region done")
+    dbg(f"timed region done: frames {t_frames * 1e3:.2f} ms, closing reduce + tonemap + barrier {(dt - t_frames) * 1e3:.2f} ms")
     t.set_option("profile_levels", 0)
 
     cnt = t.counters()
@@ -218,7 +232,7 @@ def main():
     cdev = dev if a.backend == "nccl" else torch.device("cpu")
     rays = torch.tensor([float(cnt.rays), float(cnt.shadow_rays)], dtype=torch.float64, device=cdev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if multi:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_rays, total_shadow, dt = float(rays[0].item()), float(rays[1].item()), float(tmax.item())
@@ -295,7 +309,7 @@ def main():
             out["cpu_baseline"] = {"value": round(cpu["mrays"], 2), "unit": "Mrays/s", "cores": min(os.cpu_count() or 1, 16), "kind": "port",
                                    "sample": f"{cpu['desc']} ({cpu['rays']} rays, {cpu['sec']:.1f} s), same flat BVH"}
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
