@@ -36,3 +36,22 @@ def test_bench_prints_one_json_line_with_the_contract_keys(extra):
         assert d["shadow_rays"] > 0
     else:
         assert d["shadow_rays"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_flow_runs_over_rccl_with_one_rank():
+    """BENCH_FORCE_COLLECTIVES=1: the N > 1 flow (RCCL process group, sum buffers, warm-up and closing reduce, all_reduce
+    of the counters) on the one GPU of the box; the image it tonemaps is the mean of the frames it rendered."""
+    env = dict(os.environ, BENCH_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--width", "320", "--height", "180",
+           "--cpu-seconds", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"] is not None and d["config"]["parallelism"] == "sample-striding x1"
+    # same frames, same scene: the ray count per step equals the plain run's
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    d2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert d["rays_per_step_per_gpu"] == d2["rays_per_step_per_gpu"]
