@@ -44,7 +44,7 @@ def parse():
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (default); gloo = rehearsal of the N>1 flow through host memory")
     p.add_argument("--node-width", type=int, default=0, help="BVH node layout: 0 library default, 2 fp32 BVH2, 4 quantised 4-wide")
     p.add_argument("--pipeline", type=int, default=1, help="1 (default): consecutive frames alternate between two streams so a frame's tail overlaps the next frame; 0: one stream")
-    p.add_argument("--estimator", type=int, default=0, help="0 the reference's estimator (default, the parity configuration); 1 env-map / emitter sampling with occlusion rays; 2 VNDF-sampled specular + cosine-weighted diffuse lobes")
+    p.add_argument("--estimator", type=int, default=0, help="0 the reference's estimator (default, the parity configuration); 1 env-map / emitter sampling with occlusion rays; 2 VNDF-sampled specular + cosine-weighted diffuse lobes; 3 both")
     p.add_argument("--traffic-gb", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC run (GB)")
     return p.parse_args()
 
@@ -241,7 +241,7 @@ def main():
         nn, nr = (len(x) for x in sc.bvh())
         if a.integrator == 0:    # one k_wavestack launch per frame traces every ray of the frame
             lds = sc.bvh_width == 2 and nn * 4 + nr * 3 <= 256          # <LDS scene, 4-wide nodes, light sampling>
-            kernel_name = "mipt::k_wavestack<%s, %s, %s, %s>" % tuple("true" if x else "false" for x in (lds, sc.bvh_width == 4, a.estimator == 1, a.estimator == 2))
+            kernel_name = "mipt::k_wavestack<%s, %s, %s, %s>" % tuple("true" if x else "false" for x in (lds, sc.bvh_width == 4, a.estimator in (1, 3), a.estimator >= 2))
             sec_rays, sec_ms, sec_launches = float(cnt.rays), prof.ms[0], prof.launches[0]
         else:                    # k_level<false,*> launches carry the non-primary levels
             kernel_name = "mipt::k_level<false,*>"
@@ -299,7 +299,7 @@ def main():
                        "triangles": data.triangle_count, "bvh": "sbvh" + ("-q4" if sc.bvh_width == 4 else ""), "rng": "node", "integrator": "wave-stacks" if a.integrator == 0 else "level-queues", "parallelism": f"sample-striding x{world}",
                        "env_map": None if data.env is None else "synthetic 2048x1024"},
             "spp_per_s": round(a.steps * world / dt, 3), "rays_per_step_per_gpu": round(total_rays / a.steps / world, 1),
-            "shadow_rays": round(total_shadow / a.steps / world, 1), "estimator": ("reference", "light sampling (env map + emissive triangles)", "VNDF specular + cosine diffuse lobes")[a.estimator], "kernel_ms_per_step": round(cnt.kernel_ms / a.steps, 3),
+            "shadow_rays": round(total_shadow / a.steps / world, 1), "estimator": ("reference", "light sampling (env map + emissive triangles)", "VNDF specular + cosine diffuse lobes", "VNDF + cosine lobes with light sampling")[a.estimator], "kernel_ms_per_step": round(cnt.kernel_ms / a.steps, 3),
             "level_ms": [round(prof.ms[k] / a.steps, 3) for k in range(depth)] if a.integrator else None,
             "level_mrays": [round(prof.rays[k] / a.steps / 1e6, 2) for k in range(depth)] if a.integrator else None,
             "accumulate_ms": round(prof.accumulate_ms / a.steps, 3),

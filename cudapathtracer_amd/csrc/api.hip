@@ -408,7 +408,7 @@ int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
     else if (k == "refill_lanes") { if (v < 1 || v > 64) return fail(t, MIPT_E_INVALID, "refill_lanes out of range"); t->refillLanes = v; }
     else if (k == "min_descend_lanes") { if (v < 0 || v > 64) return fail(t, MIPT_E_INVALID, "min_descend_lanes out of range"); t->minDescend = v; }
     else if (k == "pipeline_frames") t->pipelineFrames = v ? 1 : 0;
-    else if (k == "estimator") { if (v < 0 || v > 2) return fail(t, MIPT_E_INVALID, "estimator must be 0 (reference), 1 (light sampling) or 2 (VNDF + cosine lobes)"); t->estimator = v; }
+    else if (k == "estimator") { if (v < 0 || v > 3) return fail(t, MIPT_E_INVALID, "estimator must be 0 (reference), 1 (light sampling), 2 (VNDF + cosine lobes) or 3 (both)"); t->estimator = v; }
     else if (k == "profile_levels") t->profileLevels = v ? 1 : 0;
     else if (k == "integrator") { if (v != 0 && v != 1) return fail(t, MIPT_E_INVALID, "integrator must be 0 (wave stacks) or 1 (level queues)"); t->integrator = v; }
     else if (k == "blocks_per_cu") { if (v < 1 || v > 32) return fail(t, MIPT_E_INVALID, "blocks_per_cu out of range"); t->blocksPerCU = v; }
@@ -630,11 +630,11 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
     if (frame_stride == 0) frame_stride = 1;
     const uint32_t npix = W * H;
     // env-map importance sampling: wave-stack integrator with node-keyed streams only, and only with an env map to sample
-    const bool nee = t->estimator == 1;
-    if (nee && (t->rngMode != MIPT_RNG_NODE || t->integrator != 0)) return fail(t, MIPT_E_INVALID, "estimator 1 needs integrator 0 and rng_mode node");
-    if (nee && !sc->dev.envCdf && !sc->dev.nEmit) return fail(t, MIPT_E_INVALID, "estimator 1 needs a scene with an environment map or emissive triangles");
+    const bool nee = t->estimator == 1 || t->estimator == 3;
+    if (nee && (t->rngMode != MIPT_RNG_NODE || t->integrator != 0)) return fail(t, MIPT_E_INVALID, "estimators 1 and 3 need integrator 0 and rng_mode node");
+    if (nee && !sc->dev.envCdf && !sc->dev.nEmit) return fail(t, MIPT_E_INVALID, "estimators 1 and 3 need a scene with an environment map or emissive triangles");
     if (nee && npix >= (1u << 29)) return fail(t, MIPT_E_LIMIT, "viewport too large for estimator 1");
-    if (t->estimator == 2 && (t->rngMode != MIPT_RNG_NODE || t->integrator != 0)) return fail(t, MIPT_E_INVALID, "estimator 2 needs integrator 0 and rng_mode node");
+    if (t->estimator >= 2 && (t->rngMode != MIPT_RNG_NODE || t->integrator != 0)) return fail(t, MIPT_E_INVALID, "estimator 2 needs integrator 0 and rng_mode node");
 
     if (t->samplePixels < npix) {
         if (t->sample) hipFree(t->sample);

@@ -552,7 +552,7 @@ MIPT_DEV bool sample_env(const SceneDev& S, float u1, float u2, v3& dir, v3& L, 
 
 // one point on the emissive triangles, uniform by area, as seen from x (surface normal N); false when it adds nothing.
 // Lw = Le * p_cap / p_area * |cos_y| / dist^2, tmax = where the occlusion ray stops short of the emitter.
-MIPT_DEV bool sample_emitter(const SceneDev& S, float r0, float r1, float r2, v3 x, v3 N, v3& dir, v3& Lw, float& tmax) {
+MIPT_DEV bool sample_emitter(const SceneDev& S, float r0, float r1, float r2, v3 x, v3 N, float minCos, v3& dir, v3& Lw, float& tmax) {
     const uint32_t k = cdf_find(S.emitCdf, S.nEmit, r0);
     const float* E = S.emitTri + (size_t)k * 15;
     const float su = __builtin_sqrtf(r1), b1 = 1 - su, b2 = r2 * su;
@@ -561,7 +561,7 @@ MIPT_DEV bool sample_emitter(const SceneDev& S, float r0, float r1, float r2, v3
     const float dist2 = dot3(w, w), dist = __builtin_sqrtf(dist2);
     if (!(dist > 0.f)) return false;
     dir = w / dist;
-    if (!(dot3(dir, N) > 0.02f)) return false;
+    if (!(dot3(dir, N) > minCos)) return false;
     const float cosy = __builtin_fabsf(dot3(mk3(E[9], E[10], E[11]), dir));
     if (!(cosy > 0.f)) return false;
     Lw = mk3(E[12], E[13], E[14]) * (cosy * S.emitScale / dist2);
@@ -666,15 +666,22 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     // surface it lands on -- is sampled explicitly: further draws of this hit's stream (2 for the env map,
                     // then 3 for the emitters), one occlusion ray each; the child is flagged to skip those terms itself
                     opaque = mat.opacity == 1.f;
+                    constexpr float minCos = PBS ? 0.f : 0.02f;        // estimator 3: the cosine lobe covers the whole hemisphere
                     if (opaque && A.S.envCdf) {
                         const float u1 = rng.NextFloat(), u2 = rng.NextFloat();
                         v3 L; float wgt;
-                        if (sample_env(A.S, u1, u2, sdir, L, wgt) && dot3(sdir, sf.N) > 0.02f) { wantEnv = true; scon = b.f2 * (L * wgt); }
+                        if (sample_env(A.S, u1, u2, sdir, L, wgt) && dot3(sdir, sf.N) > minCos) {
+                            if constexpr (PBS) wgt = wgt * (dot3(sdir, sf.N) * 1.96f);     // (cos / pi) / p_cap: the lobe's density instead of the cap's
+                            wantEnv = true; scon = b.f2 * (L * wgt);
+                        }
                     }
                     if (opaque && A.S.nEmit) {
                         const float r0 = rng.NextFloat(), r1 = rng.NextFloat(), r2 = rng.NextFloat();
                         v3 Lw;
-                        if (sample_emitter(A.S, r0, r1, r2, b.o2, sf.N, edir, Lw, etmax)) { wantEmit = true; econ = b.f2 * Lw; }
+                        if (sample_emitter(A.S, r0, r1, r2, b.o2, sf.N, minCos, edir, Lw, etmax)) {
+                            if constexpr (PBS) Lw = Lw * (dot3(edir, sf.N) * 1.96f);
+                            wantEmit = true; econ = b.f2 * Lw;
+                        }
                     }
                 }
             }
@@ -884,7 +891,12 @@ bool wavestack_scene_in_lds(const SceneDev& S) {
 
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
     const bool lds = wavestack_scene_in_lds(a.S);
-    if (a.nee == 2u) {      // estimator 2: VNDF specular + cosine diffuse, no occlusion rays
+    if (a.nee == 3u) {      // estimator 3: the lobes of 2 with the light sampling of 1
+        if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_wavestack<false, false, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+    }
+    else if (a.nee == 2u) {      // estimator 2: VNDF specular + cosine diffuse, no occlusion rays
         if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
         else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
         else hipLaunchKernelGGL((k_wavestack<false, false, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);

@@ -156,6 +156,10 @@ int  mipt_scene_bvh_was_cached(const mipt_scene*);
  *       Diffuse: cosine-weighted about N (r = sqrt(v), dir = sqrt(1 - v) N + r cos(theta) up + r sin(theta) right, theta
  *       = 2 pi u), weight albedo * rt unchanged -- a Lambertian lobe instead of the reference's uniform cap (:518-526).
  *       Refraction unchanged.  No occlusion rays; needs integrator 0 and rng_mode node.
+ *   3 = the lobes of 2 with the light sampling of 1: the cosine-weighted diffuse child skips the environment / the
+ *       emission of the surface it lands on, and the explicitly sampled terms of estimator 1 are accepted over the
+ *       whole hemisphere (dot(dir, N) > 0) and multiplied by  (cos / pi) / p_cap = dot(dir, N) * 1.96  -- the lobe's
+ *       density in place of the cap's.  Same expectation as estimator 2.
  * Sampling tables of estimator 1 (rowCdf[envH+1], then envH rows of colCdf[envW+1]); returns the float count,
  * 0 without an env map.  No counterpart in the reference (it has no light sampling). */
 uint64_t mipt_scene_get_env_cdf(const mipt_scene*, float* out, uint64_t cap);

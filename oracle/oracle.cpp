@@ -810,7 +810,7 @@ v3 OnMiss(const Ctx& k, v3 d) {                                // :796-846
     return du * p1 + (1 - du) * p0;
 }
 // one point on the emissive triangles as seen from x (normal N); false when it adds nothing
-inline bool sample_emitter(const orc_scene& s, float r0, float r1, float r2, v3 x, v3 N, v3* dir, v3* Lw, float* tmax) {
+inline bool sample_emitter(const orc_scene& s, float r0, float r1, float r2, v3 x, v3 N, float minCos, v3* dir, v3* Lw, float* tmax) {
     const uint32_t n = (uint32_t)s.emitCdf.size() - 1;
     const uint32_t k = cdf_find(s.emitCdf.data(), n, r0);
     const float* E = &s.emitTri[(size_t)k * 15];
@@ -820,7 +820,7 @@ inline bool sample_emitter(const orc_scene& s, float r0, float r1, float r2, v3 
     const float dist2 = dot3(w, w), dist = sqrtf(dist2);
     if (!(dist > 0.f)) return false;
     *dir = w / dist;
-    if (!(dot3(*dir, N) > 0.02f)) return false;
+    if (!(dot3(*dir, N) > minCos)) return false;
     const float cosy = fabsf(dot3(ld3(E + 9), *dir));
     if (!(cosy > 0.f)) return false;
     *Lw = ld3(E + 12) * (cosy * s.emitScale / dist2);
@@ -845,7 +845,7 @@ v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noE
     v3 N = h.front ? hn : -hn;                                  // :442
     Lcg local; Lcg* rng = dfs;
     if (k.rng_mode == ORC_RNG_NODE) { local.state = node_seed(k.s0, node); rng = &local; }
-    const bool pbs = k.s->estimator == 2;                        // estimator 2: VNDF specular + cosine diffuse
+    const bool pbs = k.s->estimator >= 2;                        // estimators 2, 3: VNDF specular + cosine diffuse
     v3 mN = pbs ? GgxVisibleNormal(*rng, N, d, mat.roughness, *k.M) : GGXRandDirInsideCone(*rng, N, mat.roughness, *k.M);  // :444
     v3 R = reflect3(d, mN);                                      // :446
     v3 c = LaunchRayRecur(k, P + N * 1e-6f, R, ttl - 1, dfs, node * 2);      // :448-458
@@ -881,24 +881,27 @@ v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noE
     }
     // estimator 1: what the diffuse child would find by chance -- the environment when it escapes, the emission of the
     // surface it lands on -- is sampled explicitly instead (one occlusion ray each); the child is told to skip those terms
-    const bool nee = k.s->estimator == 1 && k.rng_mode == ORC_RNG_NODE && mat.opacity == 1.f && ttl - 1 > 0;
+    const bool nee = (k.s->estimator == 1 || k.s->estimator == 3) && k.rng_mode == ORC_RNG_NODE && mat.opacity == 1.f && ttl - 1 > 0;
+    const float minCos = pbs ? 0.f : 0.02f;                       // estimator 3: the cosine lobe covers the whole hemisphere
     const bool neeEnv = nee && !k.s->envCdf.empty(), neeEmit = nee && !k.s->emitCdf.empty();
     c = LaunchRayRecur(k, o2, d2, ttl - 1, dfs, node * 2 + 1, neeEnv, neeEmit);    // :525
     if (neeEnv) {
         float u1 = rng->NextFloat(), u2 = rng->NextFloat();
         v3 wdir, L; float wgt;
-        if (sample_env(*k.s, *k.M, u1, u2, &wdir, &L, &wgt) && dot3(wdir, N) > 0.02f) {
+        if (sample_env(*k.s, *k.M, u1, u2, &wdir, &L, &wgt) && dot3(wdir, N) > minCos) {
             k.pixel_rays++; k.c->shadow++;
             Hit sh = isect(*k.s, k.isect, o2, wdir, k.c);
+            if (pbs) wgt = wgt * (dot3(wdir, N) * 1.96f);          // (cos / pi) / p_cap: the lobe's density instead of the cap's
             if (sh.tri < 0) c = c + L * wgt;
         }
     }
     if (neeEmit) {
         float r0 = rng->NextFloat(), r1 = rng->NextFloat(), r2 = rng->NextFloat();
         v3 wdir, Lw; float tmax;
-        if (sample_emitter(*k.s, r0, r1, r2, o2, N, &wdir, &Lw, &tmax)) {
+        if (sample_emitter(*k.s, r0, r1, r2, o2, N, minCos, &wdir, &Lw, &tmax)) {
             k.pixel_rays++; k.c->shadow++;
             Hit sh = isect(*k.s, k.isect, o2, wdir, k.c);
+            if (pbs) Lw = Lw * (dot3(wdir, N) * 1.96f);
             if (!(sh.tri >= 0 && sh.t < tmax)) c = c + Lw;
         }
     }
@@ -1027,7 +1030,7 @@ int orc_scene_set_flat_bvh(orc_scene* s, const float* nodes, uint32_t n_nodes, c
     s->fwidth = 2;
     return 0;
 }
-int orc_scene_set_estimator(orc_scene* s, int e) { if (e < 0 || e > 2) return 1; s->estimator = e; return 0; }
+int orc_scene_set_estimator(orc_scene* s, int e) { if (e < 0 || e > 3) return 1; s->estimator = e; return 0; }
 uint64_t orc_scene_get_env_cdf(const orc_scene* s, float* out, uint64_t cap) {
     if (out && cap >= s->envCdf.size()) memcpy(out, s->envCdf.data(), s->envCdf.size() * sizeof(float));
     return s->envCdf.size();

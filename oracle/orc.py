@@ -176,9 +176,9 @@ class Scene:
             raise ValueError("width must be 2 or 4")
 
     def set_estimator(self, estimator):
-        """0 = the reference's estimator, 1 = light sampling, 2 = VNDF + cosine lobes (specification: include/mipt.h)."""
+        """0 = the reference's estimator, 1 = light sampling, 2 = VNDF + cosine lobes, 3 = both (specification: include/mipt.h)."""
         if lib.orc_scene_set_estimator(self.h, estimator) != 0:
-            raise ValueError("estimator must be 0, 1 or 2")
+            raise ValueError("estimator must be 0, 1, 2 or 3")
 
     def env_cdf(self):
         n = lib.orc_scene_get_env_cdf(self.h, None, 0)

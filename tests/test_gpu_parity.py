@@ -414,7 +414,7 @@ def test_light_sampling_estimator_matches_oracle(tracer, ptlib, oracle, kind, wi
             tracer.trace(sc, s, acc, ldr)
         tracer.set_option("integrator", 0)
         with pytest.raises(ptlib.MiptError):
-            tracer.set_option("estimator", 3)
+            tracer.set_option("estimator", 4)
     finally:
         tracer.set_option("estimator", 0)
         tracer.set_option("integrator", 0)
@@ -576,16 +576,18 @@ def test_refit_on_device_equals_a_fresh_scene(tracer, ptlib, oracle):
         tracer.free(acc), tracer.free(ldr)
 
 
+@pytest.mark.parametrize("est", [2, 3])
 @pytest.mark.parametrize("name,width", [("default", 4), ("default", 2), ("cornell", 0)])
-def test_estimator_2_matches_oracle(tracer, ptlib, oracle, name, width):
-    """option estimator = 2 (include/mipt.h): VNDF-sampled specular lobe with G1 weight, cosine-weighted diffuse lobe.
-    Identical ray trees, radiance to the usual tolerance, no occlusion rays; and a different image from estimator 0."""
+def test_estimator_2_and_3_match_oracle(tracer, ptlib, oracle, name, width, est):
+    """option estimator = 2 (include/mipt.h): VNDF-sampled specular lobe with G1 weight, cosine-weighted diffuse lobe;
+    3: the same with estimator 1's light sampling (occlusion rays) under the cosine lobe's density.  Identical ray trees,
+    radiance to the usual tolerance, shadow-ray counter equal to the oracle's; and a different image from estimator 0."""
     which, cam_kw, env, _, _ = MG.CONFIGS[name]
     data = MG.scene_data(name)
     sc = ptlib.Scene(tracer, data, node_width=width)
     o = oracle.Scene(data)
     o.set_flat_bvh(*sc.flat())
-    o.set_estimator(2)
+    o.set_estimator(est)
     w, h, depth = 112, 80, 7
     s = ptlib.make_settings(ptlib.make_camera(**cam_kw), w, h, depth)
     acc, ldr = dev_buffers(tracer, w, h)
@@ -594,14 +596,14 @@ def test_estimator_2_matches_oracle(tracer, ptlib, oracle, name, width):
         exp_acc = np.zeros((h, w, 4), np.float32)
         for frame in (0, 1, 9):
             s.frameID = frame
-            tracer.set_option("estimator", 2)
+            tracer.set_option("estimator", est)
             tracer.reset_counters()
             tracer.trace(sc, s, acc, ldr)
             rgb, rays = tracer.last_sample(w * h, rays=True)
             r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, frame, 1, acc=exp_acc, nthreads=16)
             assert np.array_equal(rays.reshape(h, w), r["rays"]), frame
             c = tracer.counters()
-            assert c.rays == r["stats"].rays and c.shadow_rays == 0
+            assert c.rays == r["stats"].rays and c.shadow_rays == r["stats"].shadow_rays and (c.shadow_rays > 0) == (est == 3)
             assert rel_err(rgb.reshape(h, w, 3), r["sample"]).max() < RTOL, frame
             assert rel_err(tracer.download(acc, (h, w, 4), np.float32), r["acc"]).max() < RTOL
             l = tracer.download(ldr, (h, w, 4), np.uint8)
@@ -610,7 +612,7 @@ def test_estimator_2_matches_oracle(tracer, ptlib, oracle, name, width):
         tracer.trace(sc, s, acc, ldr)
         rgb0, rays0 = tracer.last_sample(w * h, rays=True)
         assert not np.array_equal(rays0, rays) or rel_err(rgb0, rgb).max() > 1e-2      # another estimator, another image
-        tracer.set_option("estimator", 2)
+        tracer.set_option("estimator", est)
         tracer.set_option("integrator", 1)
         with pytest.raises(ptlib.MiptError):
             tracer.trace(sc, s, acc, ldr)

@@ -257,4 +257,32 @@ def test_estimator_2_specular_lobe_is_ggx(ptlib, oracle):
     albedo = float((D * G1(V[1]) * G1(CT) / (4 * V[1] * CT) * CT).mean() * 2 * np.pi)
     assert 0.5 < albedo < 0.6 and abs(float(r["acc"][..., :3].mean()) - albedo) < 0.012, albedo
     with pytest.raises(ValueError):
-        o.set_estimator(3)
+        o.set_estimator(4)
+
+
+@pytest.mark.parametrize("scene", ["default-env", "cornell-emitters"])
+def test_estimator_3_is_estimator_2_with_light_sampling(ptlib, oracle, scene):
+    """estimator 3 = the lobes of estimator 2 + the explicit light sampling of estimator 1 with the cosine lobe's density
+    in place of the cap's: same mean image as estimator 2, occlusion rays present, less noise under concentrated light."""
+    if scene == "default-env":
+        data, cam, frames, tol = ptlib.builtin_scene(1, _patchy_env()), ptlib.DEFAULT_CAMERA, 160, 0.03
+    else:
+        data, cam, frames, tol = ptlib.builtin_scene(0), ptlib.CORNELL_CAMERA, 300, 0.03
+    o = oracle.Scene(data)
+    o.set_flat_bvh(*ptlib.Scene(None, data).flat())
+    s = ptlib.make_settings(ptlib.make_camera(**cam), 48, 32, 4)
+    imgs, stats = {}, {}
+    for est in (2, 3):
+        o.set_estimator(est)
+        r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, frames, want_ldr=False)
+        imgs[est] = r["acc"][..., :3].astype(np.float64); stats[est] = r["stats"]
+    assert stats[2].shadow_rays == 0 and 0 < stats[3].shadow_rays < stats[3].rays
+    assert abs(imgs[3].mean() / imgs[2].mean() - 1) < tol, (imgs[3].mean(), imgs[2].mean())
+    blocks = {e: im.reshape(2, 16, 3, 16, 3).mean((1, 3)) for e, im in imgs.items()}
+    assert np.abs(blocks[3] / blocks[2] - 1).mean() < 0.08
+    dev = {}
+    for est in (2, 3):
+        o.set_estimator(est)
+        one = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 500, 1, want_ldr=False)["sample"]
+        dev[est] = np.sqrt(((one - imgs[est]) ** 2).mean())
+    assert dev[3] < dev[2]
