@@ -42,7 +42,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys(extra):
 def test_bench_multi_gpu_flow_runs_over_rccl_with_one_rank():
     """BENCH_FORCE_COLLECTIVES=1: the N > 1 flow (RCCL process group, sum buffers, warm-up and closing reduce, all_reduce
     of the counters) on the one GPU of the box; the image it tonemaps is the mean of the frames it rendered."""
-    env = dict(os.environ, BENCH_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ, BENCH_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--width", "320", "--height", "180",
            "--cpu-seconds", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
