@@ -33,6 +33,7 @@ struct mipt_tracer {
     int64_t blocksPerCU = 4;         // resident 256-thread blocks per CU of the persistent kernels
     int64_t refillLanes = 8;
     int64_t minDescend = 0;
+    int64_t xcdBands = -1;             // -1 auto, 0 one pixel counter, 1 one band of the frame per XCD
     int64_t estimator = 0;
     int64_t profileLevels = 0;
     int64_t integrator = 0;          // 0 persistent wave stacks, 1 level-synchronous queues
@@ -407,6 +408,7 @@ int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
     else if (k == "count_pixel_rays") t->countPixelRays = v ? 1 : 0;
     else if (k == "refill_lanes") { if (v < 1 || v > 64) return fail(t, MIPT_E_INVALID, "refill_lanes out of range"); t->refillLanes = v; }
     else if (k == "min_descend_lanes") { if (v < 0 || v > 64) return fail(t, MIPT_E_INVALID, "min_descend_lanes out of range"); t->minDescend = v; }
+    else if (k == "xcd_bands") { if (v < -1 || v > 1) return fail(t, MIPT_E_INVALID, "xcd_bands must be -1 (auto), 0 or 1"); t->xcdBands = v; }
     else if (k == "pipeline_frames") t->pipelineFrames = v ? 1 : 0;
     else if (k == "estimator") { if (v < 0 || v > 3) return fail(t, MIPT_E_INVALID, "estimator must be 0 (reference), 1 (light sampling), 2 (VNDF + cosine lobes) or 3 (both)"); t->estimator = v; }
     else if (k == "profile_levels") t->profileLevels = v ? 1 : 0;
@@ -766,6 +768,11 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
             const bool ldsScene = wavestack_scene_in_lds(sc->dev);
             SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (ldsScene ? 8 : 24));
             SA.pixCounter = counts; SA.nee = (uint32_t)t->estimator;
+            // xcd_bands auto: on when nodes + references exceed one XCD's 4 MiB L2 (10 M-triangle grid: +3-4 %), off for
+            // cache-resident scenes, where the bands only lengthen the frame's tail (Cornell -2 %, Default -0.5 %;
+            // profiles/r1/exp_xcd_bands.log)
+            const size_t workingSet = (size_t)sc->dev.nNodes * 64 + (size_t)sc->dev.nRefs * 48;
+            SA.xcdBands = (uint32_t)(t->xcdBands >= 0 ? t->xcdBands : (workingSet > (4u << 20) ? 1 : 0));
             SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npixPart; SA.band = band;
             mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
             if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, S)); }

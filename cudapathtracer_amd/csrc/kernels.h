@@ -66,7 +66,11 @@ struct StackArgs {
     uint32_t minDescend;         // a traversal round stops descending when fewer lanes than this are still at inner nodes
     uint32_t nee;                // option "estimator": 0 the reference's, 1 light sampling (occlusion rays), 2 VNDF + cosine lobes
     uint32_t cap;                // entries per wave
-    uint32_t* pixCounter;        // next unclaimed pixel of the frame (reset to 0 before the launch)
+    uint32_t* pixCounter;        // next unclaimed pixel of the frame (reset to 0 before the launch); with xcdBands: 8
+                                 // counters, 8 words apart, one per band
+    uint32_t xcdBands;           // 0: one pixel counter.  1: the frame is cut into 8 bands of consecutive pixels and a block
+                                 // claims from band blockIdx % 8 first (blocks b and b + 8 share an XCD and its L2), then
+                                 // from the bands after it until all are dry
     float* sample; uint32_t* pixelRays; unsigned long long* stats;
     uint32_t pix0, npix;         // npix: pixels of this handle's partition (the whole frame without one)
     Band band;

@@ -611,6 +611,8 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     uint32_t nF = 0, nT = 0;          // parked records: "full" ones (will spawn children) fill the queue from slot 0 up,
                                       // "terminal" ones (miss, or hit at the last level: emission only) from the top down
     bool more = true;
+    uint32_t curBand = blockIdx.x & 7u, bandsDry = 0;                 // xcdBands: the band this wave claims from now
+    const uint32_t bandLen = ((A.npix + 7u) / 8u + 63u) & ~63u;
     // per-lane traversal state
     bool active = false;
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), beta = mk3(0, 0, 0);
@@ -749,10 +751,27 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
             uint32_t got = 0, pbase = 0;
             if (more && take < idle) {
                 const uint32_t want = idle - take;
-                if (lane == 0) pbase = atomicAdd(A.pixCounter, want);
-                pbase = __builtin_amdgcn_readfirstlane(pbase);
-                got = pbase < A.npix ? (A.npix - pbase < want ? A.npix - pbase : want) : 0u;
-                if (got < want) more = false;
+                if (A.xcdBands) {
+                    // one band of the frame per XCD: the rays of neighbouring pixels walk the same part of the BVH, so an
+                    // XCD's L2 holds an eighth of what the frame's front touches instead of all of it.  A dry band stays
+                    // dry (its counter only grows), so a wave moves on through the bands once and is done after eight.
+                    while (more) {
+                        const uint32_t lo = curBand * bandLen, hi = lo + bandLen < A.npix ? lo + bandLen : A.npix;
+                        if (lane == 0) pbase = atomicAdd(A.pixCounter + curBand * 8u, want);
+                        pbase = __builtin_amdgcn_readfirstlane(pbase);
+                        const uint32_t len = hi > lo ? hi - lo : 0u;
+                        got = pbase < len ? (len - pbase < want ? len - pbase : want) : 0u;
+                        pbase += lo;
+                        if (got) break;
+                        curBand = (curBand + 1u) & 7u;
+                        if (++bandsDry == 8u) more = false;
+                    }
+                } else {
+                    if (lane == 0) pbase = atomicAdd(A.pixCounter, want);
+                    pbase = __builtin_amdgcn_readfirstlane(pbase);
+                    got = pbase < A.npix ? (A.npix - pbase < want ? A.npix - pbase : want) : 0u;
+                    if (got < want) more = false;
+                }
             }
             sp -= take;
             MIPT_PROF(pf[10]++; pf[11] += take + got;)

@@ -686,3 +686,52 @@ def test_tile_partition_renders_each_pixel_as_the_full_frame_does(tracer, ptlib)
         tracer.set_option("count_pixel_rays", 0)
         for b in (acc, ldr, acc2, ldr2):
             tracer.free(b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,w,h,depth", [("default", 200, 120, 6), ("cornell", 67, 45, 5), ("default", 5, 3, 4), ("cornell", 1, 1, 3)])
+def test_xcd_bands_render_the_same_frame(tracer, ptlib, oracle, name, w, h, depth):
+    """Option xcd_bands (automatic for scenes larger than an XCD's L2): the frame is claimed as eight bands, one per XCD
+    first, then whatever the others have left.  Who renders a pixel changes nothing about its sample: identical ray
+    trees against the oracle, radiance within RTOL -- also for frames with fewer pixels than bands, under a row-tile
+    partition, and over pipelined frames."""
+    which, cam_kw, env, _, _ = MG.CONFIGS[name]
+    data = MG.scene_data(name)
+    sc = ptlib.Scene(tracer, data)
+    o = oracle.Scene(data)
+    o.set_flat_bvh(*sc.flat())
+    s = ptlib.make_settings(ptlib.make_camera(**cam_kw), w, h, depth)
+    acc, ldr = dev_buffers(tracer, w, h)
+    tracer.set_option("xcd_bands", 1)
+    tracer.set_option("count_pixel_rays", 1)
+    try:
+        exp_acc = np.zeros((h, w, 4), np.float32)
+        for frame in (0, 1):
+            s.frameID = frame
+            tracer.trace(sc, s, acc, ldr)
+            rgb, rays = tracer.last_sample(w * h, rays=True)
+            r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, frame, 1, acc=exp_acc, nthreads=16)
+            assert np.array_equal(rays.reshape(h, w), r["rays"]), frame
+            assert rel_err(rgb.reshape(h, w, 3), r["sample"]).max() < RTOL, frame
+        full = tracer.download(acc, (h, w, 4), np.float32)
+        assert rel_err(full, r["acc"]).max() < RTOL
+        tracer.set_option("count_pixel_rays", 0)
+        s.frameID = 0
+        if h >= 8:
+            tracer.memset(acc, 0, w * h * 16)
+            for part in range(3):
+                tracer.set_tile_partition(8, 3, part)
+                tracer.render(sc, s, 0, 2, acc, ldr)
+            tracer.set_tile_partition(0, 1, 0)
+            assert rel_err(tracer.download(acc, (h, w, 4), np.float32), full).max() < RTOL
+        tracer.memset(acc, 0, w * h * 16)
+        tracer.render(sc, s, 0, 2, acc, ldr)                     # pipelined frames
+        assert rel_err(tracer.download(acc, (h, w, 4), np.float32), full).max() < RTOL
+        with pytest.raises(ptlib.MiptError):
+            tracer.set_option("xcd_bands", 2)
+    finally:
+        tracer.set_tile_partition(0, 1, 0)
+        tracer.set_option("xcd_bands", -1)
+        tracer.set_option("count_pixel_rays", 0)
+        s.frameID = 0
+        tracer.free(acc), tracer.free(ldr)
