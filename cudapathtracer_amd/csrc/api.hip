@@ -768,11 +768,13 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
             const bool ldsScene = wavestack_scene_in_lds(sc->dev);
             SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (ldsScene ? 8 : 24));
             SA.pixCounter = counts; SA.nee = (uint32_t)t->estimator;
-            // xcd_bands auto: on when nodes + references exceed one XCD's 4 MiB L2 (10 M-triangle grid: +3-4 %), off for
-            // cache-resident scenes, where the bands only lengthen the frame's tail (Cornell -2 %, Default -0.5 %;
-            // profiles/r1/exp_xcd_bands.log)
+            // xcd_bands auto: on when nodes + references exceed one XCD's 4 MiB L2 or the frame has 4 Mi pixels or more.
+            // Eight counters also spread the claims (one word sustains ~90 atomics/us, MI355X_MICROARCH.md; frames of cheap
+            // pixels come close to that), which fits the gain growing as the pixels get cheaper: 4K grids
+            // of 1.8 k ... 10 M triangles +32 ... +4 %, Cornell / Default at 4K +0.5 %; at 1080p the cache-resident
+            // scenes lose to a longer tail (Cornell -2 %, Default -0.5 %) and keep one counter (profiles/r1/exp_xcd_bands.log)
             const size_t workingSet = (size_t)sc->dev.nNodes * 64 + (size_t)sc->dev.nRefs * 48;
-            SA.xcdBands = (uint32_t)(t->xcdBands >= 0 ? t->xcdBands : (workingSet > (4u << 20) ? 1 : 0));
+            SA.xcdBands = (uint32_t)(t->xcdBands >= 0 ? t->xcdBands : ((workingSet > (4u << 20) || npixPart >= (1u << 22)) ? 1 : 0));
             SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npixPart; SA.band = band;
             mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
             if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, S)); }
