@@ -60,6 +60,11 @@ class Counters(C.Structure):
                 ("shadow_rays", C.c_uint64)]
 
 
+class IssueResult(C.Structure):
+    _fields_ = [("ms", C.c_double), ("wave_instructions", C.c_uint64), ("waves", C.c_uint32), ("simds", C.c_uint32),
+                ("median_cycles", C.c_double), ("max_cycles", C.c_double), ("median_realtime_ticks", C.c_double)]
+
+
 class LevelProfile(C.Structure):
     _fields_ = [("rays", C.c_uint64 * 32), ("ms", C.c_double * 32), ("launches", C.c_uint64 * 32), ("accumulate_ms", C.c_double)]
 
@@ -99,6 +104,9 @@ lib.mipt_scene_bvh_width.argtypes = [_vp]
 lib.mipt_scene_bvh_width.restype = C.c_uint32
 lib.mipt_trace.argtypes = [_vp, _vp, C.POINTER(Settings), _vp, _vp]
 lib.mipt_render.argtypes = [_vp, _vp, C.POINTER(Settings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _vp, _vp]
+lib.mipt_buffer_async_gpu_push_on.argtypes = [_vp, _vp]
+lib.mipt_buffer_set_cpu_data.argtypes = [_vp, _vp]
+lib.mipt_buffer_set_gpu_data.argtypes = [_vp, _vp]
 lib.mipt_tonemap.argtypes = [_vp, _vp, C.c_float, C.c_uint32, _vp]
 lib.mipt_last_sample.argtypes = [_vp, _vp, _vp, C.c_uint32]
 lib.mipt_trace_rays.argtypes = [_vp, _vp, _vp, _vp, C.c_uint32, _vp]
@@ -135,6 +143,7 @@ lib.mipt_rgbe_decode.argtypes = [_vp, C.c_size_t, _vp, C.POINTER(C.c_uint32), C.
 lib.mipt_rgbe_encode.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp, C.c_size_t]
 lib.mipt_rgbe_encode.restype = C.c_size_t
 lib.mipt_test_math.argtypes = [_vp, C.c_int, _vp, _vp, C.c_uint32, _vp]
+lib.mipt_test_issue.argtypes = [_vp, C.c_uint32, C.c_uint32, C.POINTER(IssueResult)]
 
 
 class MiptError(RuntimeError):
@@ -422,6 +431,12 @@ class Tracer:
         out = np.zeros_like(a)
         self._chk(lib.mipt_test_math(self.h, fn, _ptr(a), _ptr(b), len(a), _ptr(out)), "test_math")
         return out
+
+    def test_issue(self, blocks_per_cu, iters):
+        """VALU issue calibration (csrc/microbench.hip): returns an IssueResult."""
+        r = IssueResult()
+        self._chk(lib.mipt_test_issue(self.h, blocks_per_cu, iters, C.byref(r)), "test_issue")
+        return r
 
     def close(self):
         if self.h:

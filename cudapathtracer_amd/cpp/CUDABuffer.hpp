@@ -4,6 +4,8 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 
@@ -47,6 +49,16 @@ public:
     void* mutable_gpu_data() { return const_cast<void*>(need(mipt_buffer_mutable_gpu_data(_b))); }
     SyncedHead head() const { return (SyncedHead)mipt_buffer_head(_b); }
     size_t size() const { return mipt_buffer_size(_b); }
+    // non-owning adoption of caller memory (CUDABuffer.hpp:18,20): at least size() bytes; the head moves to that side
+    void set_cpu_data(void* data) { detail::Check(mipt_buffer_set_cpu_data(_b, data), "mipt_buffer_set_cpu_data"); }
+    void set_gpu_data(void* data) { detail::Check(mipt_buffer_set_gpu_data(_b, data), "mipt_buffer_set_gpu_data"); }
+    // async_gpu_push(const cudaStream_t&) (CUDABuffer.hpp:27): Stream is the caller's hipStream_t (any pointer-sized
+    // handle; this header includes no HIP); without an argument the copy goes onto the tracer's own stream
+    template <typename Stream> void async_gpu_push(const Stream& stream) {
+        static_assert(sizeof(Stream) == sizeof(void*), "async_gpu_push takes a hipStream_t");
+        void* s = nullptr; std::memcpy(&s, &stream, sizeof s);
+        detail::Check(mipt_buffer_async_gpu_push_on(_b, s), "mipt_buffer_async_gpu_push_on");
+    }
     void async_gpu_push() { detail::Check(mipt_buffer_async_gpu_push(_b), "mipt_buffer_async_gpu_push"); }
 
 private:

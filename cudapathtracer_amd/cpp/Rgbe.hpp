@@ -40,6 +40,13 @@ inline bool Decode(const unsigned char* p, size_t n, std::vector<float>& rgb, in
         if (l.empty()) break;
     }
     if (!format || !line(l) || std::sscanf(l.c_str(), "-Y %d +X %d", &height, &width) != 2 || width <= 0 || height <= 0) return false;
+    {   // the header is untrusted: no allocation before the pixel count is known to fit the bytes that follow.  Flat data
+        // takes 4 bytes per pixel; a run-length scanline at least its 4-byte marker plus, per channel, 2 bytes per run of
+        // at most 127 pixels.
+        const unsigned long long W = (unsigned long long)width, H = (unsigned long long)height, left = n - pos;
+        const unsigned long long flatBytes = W * H * 4ull, rleBytes = H * (4ull + 4ull * 2ull * ((W + 126ull) / 127ull));
+        if ((flatBytes < rleBytes ? flatBytes : rleBytes) > left) return false;
+    }
     rgb.assign((size_t)width * height * 3, 0.f);
     std::vector<unsigned char> scan((size_t)width * 4);
     float* out = rgb.data();

@@ -39,6 +39,7 @@ struct mipt_tracer {
     int64_t integrator = 0;          // 0 persistent wave stacks, 1 level-synchronous queues
     uint32_t tileRows = 0, tileParts = 1, tilePart = 0;     // mipt_set_tile_partition (tileParts 1: the whole frame)
     int64_t pipelineFrames = 1;      // consecutive frames alternate between two streams / buffer sets (see mipt_render)
+    int64_t keepSample = 0;          // 1: a pipelined frame's sample buffer survives its fold (mipt_last_sample), at the price of one clear per frame
     // work buffers
     Queue wstack = {}; size_t wstackEntries = 0;
     Queue q[2] = {};
@@ -56,7 +57,10 @@ struct mipt_tracer {
     float* ring[kRing] = {}; size_t ringPixels = 0;          // ring[0] aliases `sample`
     hipEvent_t kernEv[kRing] = {}, foldEv[kRing] = {};       // integrator of / fold of the frame that last used the slot
     bool foldValid[kRing] = {};
-    hipEvent_t joinEv = nullptr;
+    size_t slotDirty[kRing] = {};    // pixels of the slot (from its start) that hold a sample no fold has cleared: the next frame using it clears them first
+    bool sampleConsumed = false;     // the most recent frame left no sample behind (fold cleared it / summed straight into acc)
+    std::vector<hipEvent_t> freeEvents;      // timing events are pooled: created at the high-water mark, reused, destroyed with the tracer
+    hipEvent_t joinEv = nullptr, joinEv2 = nullptr;
     bool pipeBusy = false;           // frames are in flight that `stream` has not been ordered after yet
     bool mainTouched = true;         // something other than a pipelined frame was enqueued on `stream` since aux/fold last waited on it
     uint32_t flip = 0;               // frames rendered through the pipeline
@@ -87,6 +91,7 @@ struct mipt_scene {
 struct mipt_buffer {
     mipt_tracer* t = nullptr;
     void* cpu = nullptr; void* gpu = nullptr; size_t size = 0; int head = MIPT_HEAD_UNINITIALIZED;
+    bool ownCpu = false, ownGpu = false;      // false: memory handed in through mipt_buffer_set_*_data (never freed here)
 };
 
 namespace {
@@ -99,9 +104,12 @@ int use_device(mipt_tracer* t) { hipError_t e = hipSetDevice(t->device); if (e !
 // Orders `stream` after everything the frame pipeline has put on `aux`, so that whatever the caller does next on the
 // tracer's stream (read-back, tonemap, synchronize ...) sees every frame rendered so far.
 void join_aux(mipt_tracer* t) {
-    if (t->pipeBusy && t->fold && t->joinEv) {       // every pipelined frame ends with its fold on `fold`, in frame order
+    if (t->pipeBusy && t->fold && t->joinEv) {
+        // a pipelined frame ends with its fold on `fold` (in frame order), or -- summed straight into the caller's
+        // buffer -- with its integrator on `stream` / `aux`
         hipEventRecord(t->joinEv, t->fold);
         hipStreamWaitEvent(t->stream, t->joinEv, 0);
+        if (t->joinEv2) { hipEventRecord(t->joinEv2, t->aux); hipStreamWaitEvent(t->stream, t->joinEv2, 0); }
         t->pipeBusy = false;
     }
     t->mainTouched = true;
@@ -122,11 +130,21 @@ int ensure_queue(mipt_tracer* t, int which, size_t cap) {
     return MIPT_OK;
 }
 
+// Timing events come from a pool owned by the tracer (the per-frame hipEventCreate / hipEventDestroy pairs of the
+// first version sat in the hot loop and leaked on an early return).
+hipEvent_t take_event(mipt_tracer* t) {
+    if (!t->freeEvents.empty()) { hipEvent_t e = t->freeEvents.back(); t->freeEvents.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+void give_event(mipt_tracer* t, hipEvent_t e) { if (e) t->freeEvents.push_back(e); }
+
 void resolve_events(mipt_tracer* t) {
     for (auto& p : t->pending) {
         float ms = 0.f;
         if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) t->kernelMs += ms;
-        hipEventDestroy(p.first); hipEventDestroy(p.second);
+        give_event(t, p.first); give_event(t, p.second);
     }
     t->pending.clear();
     for (auto& p : t->levelPending) {
@@ -134,7 +152,7 @@ void resolve_events(mipt_tracer* t) {
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             if (p.level >= 0) { t->levelMs[p.level] += ms; t->levelLaunches[p.level]++; } else t->accumulateMs += ms;
         }
-        hipEventDestroy(p.a); hipEventDestroy(p.b);
+        give_event(t, p.a); give_event(t, p.b);
     }
     t->levelPending.clear();
 }
@@ -161,6 +179,9 @@ struct BvhCacheHeader {
     uint64_t key;               // hash of the triangle positions and the build parameters
     uint32_t nTris, nNodes, nRefs, width;
 };
+// Bump kBvhBuilderVersion with any change to the builders, the 4-wide collapse or the quantiser: a cache file written by
+// an earlier build must not be accepted (load_bvh_cache re-validates structure, not that boxes enclose their triangles).
+constexpr uint64_t kBvhBuilderVersion = 2;
 uint64_t bvh_cache_key(const std::vector<TriPos>& tris, const BvhParams& bp) {
     uint64_t h = 0xcbf29ce484222325ull;
     auto mix = [&](uint64_t w) { h = (h ^ w) * 0x100000001b3ull; h ^= h >> 29; };
@@ -171,6 +192,7 @@ uint64_t bvh_cache_key(const std::vector<TriPos>& tris, const BvhParams& bp) {
     if (i < n) mix(w[i]);
     uint32_t a, c; memcpy(&a, &bp.splitAlpha, 4); memcpy(&c, &bp.triCost, 4);
     mix(bp.builder); mix(bp.maxLeafSize); mix(a); mix(c); mix(tris.size()); mix(bp.nodeWidth);
+    mix(kBvhBuilderVersion); mix(bvh_build_constants_hash());
     return h;
 }
 bool load_bvh_cache(const char* path, uint64_t key, uint32_t nTris, uint32_t width, BvhOut& bo) {
@@ -309,47 +331,59 @@ void fill_materials(const mipt_scene_desc* d, std::vector<float>& mats) {
     }
 }
 
+// include/mipt.h promises that no entry point throws: every body that can allocate on the host (vectors, strings,
+// the builder's worker threads) runs inside this guard.
+template <typename F> int guarded(mipt_tracer* t, F&& body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc&) { try { if (t) t->err = "out of host memory"; } catch (...) {} return MIPT_E_NOMEM; }
+    catch (const std::exception& e) { try { if (t) t->err = std::string("exception: ") + e.what(); } catch (...) {} return MIPT_E_INVALID; }
+    catch (...) { try { if (t) t->err = "unknown exception"; } catch (...) {} return MIPT_E_INVALID; }
+}
+
 }  // namespace
 
 extern "C" {
 
 // ---------------------------------------------------------------------------------------------------------------
 int mipt_create(int device, mipt_tracer** out) {
-    if (!out) return MIPT_E_INVALID;
-    *out = nullptr;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MIPT_E_NODEVICE;
-    if (device < 0 || device >= n) return MIPT_E_INVALID;
-    mipt_tracer* t = new mipt_tracer();
-    t->device = device;
-    if (hipSetDevice(device) != hipSuccess) { delete t; return MIPT_E_HIP; }
-    int cu = 0;
-    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) t->numCU = cu;
-    if (hipStreamCreateWithFlags(&t->own, hipStreamNonBlocking) != hipSuccess) { delete t; return MIPT_E_HIP; }
-    t->stream = t->own;
-    // (all three streams at normal priority: a high-priority fold stream bought nothing, and when two processes share
-    // one GPU its queue, parked on an event wait, kept the queue that had to signal it from being scheduled)
-    bool ok = hipStreamCreateWithFlags(&t->aux, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&t->fold, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&t->joinEv, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < mipt_tracer::kRing && ok; i++)
-        ok = hipEventCreateWithFlags(&t->kernEv[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&t->foldEv[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-        mipt_destroy(t); return MIPT_E_HIP;
-    }
-    if (hipMalloc((void**)&t->counts, 64 * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&t->stats, 40 * sizeof(unsigned long long)) != hipSuccess) {
-        mipt_destroy(t); return MIPT_E_NOMEM;
-    }
-    hipMemsetAsync(t->stats, 0, 40 * sizeof(unsigned long long), t->stream);
-    // A stream gets its hardware queue at its first command, and a process has few of them (GPU_MAX_HW_QUEUES, 4 by
-    // default): streams beyond that share queues, and two frames on one queue cannot overlap.  Take the queues of the
-    // pipeline's streams now, before whatever the host application creates later (an RCCL communicator created first
-    // cost the frame pipeline its overlap: 6.2 -> 7.1 ms per Cornell frame).
-    hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), t->aux);
-    hipEventRecord(t->joinEv, t->fold);
-    hipStreamSynchronize(t->stream); hipStreamSynchronize(t->aux); hipStreamSynchronize(t->fold);
-    *out = t;
-    return MIPT_OK;
+    return guarded(nullptr, [&]() -> int {
+        if (!out) return MIPT_E_INVALID;
+        *out = nullptr;
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MIPT_E_NODEVICE;
+        if (device < 0 || device >= n) return MIPT_E_INVALID;
+        mipt_tracer* t = new mipt_tracer();
+        t->device = device;
+        if (hipSetDevice(device) != hipSuccess) { delete t; return MIPT_E_HIP; }
+        int cu = 0;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) t->numCU = cu;
+        if (hipStreamCreateWithFlags(&t->own, hipStreamNonBlocking) != hipSuccess) { delete t; return MIPT_E_HIP; }
+        t->stream = t->own;
+        // (all three streams at normal priority: a high-priority fold stream bought nothing, and when two processes share
+        // one GPU its queue, parked on an event wait, kept the queue that had to signal it from being scheduled)
+        bool ok = hipStreamCreateWithFlags(&t->aux, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&t->fold, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&t->joinEv, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&t->joinEv2, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < mipt_tracer::kRing && ok; i++)
+            ok = hipEventCreateWithFlags(&t->kernEv[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&t->foldEv[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            mipt_destroy(t); return MIPT_E_HIP;
+        }
+        if (hipMalloc((void**)&t->counts, 64 * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&t->stats, 40 * sizeof(unsigned long long)) != hipSuccess) {
+            mipt_destroy(t); return MIPT_E_NOMEM;
+        }
+        hipMemsetAsync(t->stats, 0, 40 * sizeof(unsigned long long), t->stream);
+        // A stream gets its hardware queue at its first command, and a process has few of them (GPU_MAX_HW_QUEUES, 4 by
+        // default): streams beyond that share queues, and two frames on one queue cannot overlap.  Take the queues of the
+        // pipeline's streams now, before whatever the host application creates later (an RCCL communicator created first
+        // cost the frame pipeline its overlap: 6.2 -> 7.1 ms per Cornell frame).
+        hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), t->aux);
+        hipEventRecord(t->joinEv, t->fold);
+        hipStreamSynchronize(t->stream); hipStreamSynchronize(t->aux); hipStreamSynchronize(t->fold);
+        *out = t;
+        return MIPT_OK;
+    });
 }
 
 void mipt_destroy(mipt_tracer* t) {
@@ -364,6 +398,8 @@ void mipt_destroy(mipt_tracer* t) {
     if (t->counts2) hipFree(t->counts2);
     for (int i = 0; i < mipt_tracer::kRing; i++) { if (t->kernEv[i]) hipEventDestroy(t->kernEv[i]); if (t->foldEv[i]) hipEventDestroy(t->foldEv[i]); }
     if (t->joinEv) hipEventDestroy(t->joinEv);
+    if (t->joinEv2) hipEventDestroy(t->joinEv2);
+    for (hipEvent_t e : t->freeEvents) hipEventDestroy(e);
     if (t->fold) hipStreamDestroy(t->fold);
     if (t->aux) hipStreamDestroy(t->aux);
     if (t->counts) hipFree(t->counts);
@@ -377,84 +413,99 @@ void mipt_destroy(mipt_tracer* t) {
 const char* mipt_last_error(const mipt_tracer* t) { return t ? t->err.c_str() : "null tracer"; }
 
 int mipt_set_stream(mipt_tracer* t, void* s) {
-    if (!t) return MIPT_E_INVALID;
-    if (use(t)) return MIPT_E_HIP;                   // the old stream is ordered after the pipeline's aux stream first
-    hipStream_t ns = s ? (hipStream_t)s : t->own;
-    if (ns != t->stream) hipStreamSynchronize(t->stream);
-    t->stream = ns;
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t) return MIPT_E_INVALID;
+        if (use(t)) return MIPT_E_HIP;                   // the old stream is ordered after the pipeline's aux stream first
+        hipStream_t ns = s ? (hipStream_t)s : t->own;
+        if (ns != t->stream) hipStreamSynchronize(t->stream);
+        t->stream = ns;
+        return MIPT_OK;
+    });
 }
 
 int mipt_synchronize(mipt_tracer* t) {
-    if (!t) return MIPT_E_INVALID;
-    if (use(t)) return MIPT_E_HIP;
-    HIPCHK(t, hipStreamSynchronize(t->stream));
-    resolve_events(t);
-    unsigned long long flag = 0;
-    HIPCHK(t, hipMemcpy(&flag, t->stats + 39, sizeof flag, hipMemcpyDeviceToHost));
-    if (flag) {
-        hipMemset(t->stats + 39, 0, sizeof flag);
-        return fail(t, MIPT_E_LIMIT, "wave stack overflow: a frame lost rays (raise the per-wave capacity)");
-    }
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t) return MIPT_E_INVALID;
+        if (use(t)) return MIPT_E_HIP;
+        HIPCHK(t, hipStreamSynchronize(t->stream));
+        resolve_events(t);
+        unsigned long long flag = 0;
+        HIPCHK(t, hipMemcpy(&flag, t->stats + 39, sizeof flag, hipMemcpyDeviceToHost));
+        if (flag) {
+            hipMemset(t->stats + 39, 0, sizeof flag);
+            return fail(t, MIPT_E_LIMIT, "wave stack overflow: a frame lost rays (raise the per-wave capacity)");
+        }
+        return MIPT_OK;
+    });
 }
 
 int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
-    if (!t || !key) return MIPT_E_INVALID;
-    std::string k(key);
-    if (k == "tile_pixels") { if (v < 0) return fail(t, MIPT_E_INVALID, "tile_pixels < 0"); t->tilePixels = v; }
-    else if (k == "queue_budget_mb") { if (v < 1) return fail(t, MIPT_E_INVALID, "queue_budget_mb < 1"); t->queueBudgetMB = v; }
-    else if (k == "rng_mode") { if (v != MIPT_RNG_NODE && v != MIPT_RNG_DFS) return fail(t, MIPT_E_INVALID, "bad rng_mode"); t->rngMode = v; }
-    else if (k == "count_pixel_rays") t->countPixelRays = v ? 1 : 0;
-    else if (k == "refill_lanes") { if (v < 1 || v > 64) return fail(t, MIPT_E_INVALID, "refill_lanes out of range"); t->refillLanes = v; }
-    else if (k == "min_descend_lanes") { if (v < 0 || v > 64) return fail(t, MIPT_E_INVALID, "min_descend_lanes out of range"); t->minDescend = v; }
-    else if (k == "xcd_bands") { if (v < -1 || v > 1) return fail(t, MIPT_E_INVALID, "xcd_bands must be -1 (auto), 0 or 1"); t->xcdBands = v; }
-    else if (k == "pipeline_frames") t->pipelineFrames = v ? 1 : 0;
-    else if (k == "estimator") { if (v < 0 || v > 3) return fail(t, MIPT_E_INVALID, "estimator must be 0 (reference), 1 (light sampling), 2 (VNDF + cosine lobes) or 3 (both)"); t->estimator = v; }
-    else if (k == "profile_levels") t->profileLevels = v ? 1 : 0;
-    else if (k == "integrator") { if (v != 0 && v != 1) return fail(t, MIPT_E_INVALID, "integrator must be 0 (wave stacks) or 1 (level queues)"); t->integrator = v; }
-    else if (k == "blocks_per_cu") { if (v < 1 || v > 32) return fail(t, MIPT_E_INVALID, "blocks_per_cu out of range"); t->blocksPerCU = v; }
-    else return fail(t, MIPT_E_INVALID, "unknown option " + k);
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t || !key) return MIPT_E_INVALID;
+        std::string k(key);
+        if (k == "tile_pixels") { if (v < 0) return fail(t, MIPT_E_INVALID, "tile_pixels < 0"); t->tilePixels = v; }
+        else if (k == "queue_budget_mb") { if (v < 1) return fail(t, MIPT_E_INVALID, "queue_budget_mb < 1"); t->queueBudgetMB = v; }
+        else if (k == "rng_mode") { if (v != MIPT_RNG_NODE && v != MIPT_RNG_DFS) return fail(t, MIPT_E_INVALID, "bad rng_mode"); t->rngMode = v; }
+        else if (k == "count_pixel_rays") t->countPixelRays = v ? 1 : 0;
+        else if (k == "refill_lanes") { if (v < 1 || v > 64) return fail(t, MIPT_E_INVALID, "refill_lanes out of range"); t->refillLanes = v; }
+        else if (k == "min_descend_lanes") { if (v < 0 || v > 64) return fail(t, MIPT_E_INVALID, "min_descend_lanes out of range"); t->minDescend = v; }
+        else if (k == "xcd_bands") { if (v < -1 || v > 1) return fail(t, MIPT_E_INVALID, "xcd_bands must be -1 (auto), 0 or 1"); t->xcdBands = v; }
+        else if (k == "pipeline_frames") t->pipelineFrames = v ? 1 : 0;
+        else if (k == "keep_sample") t->keepSample = v ? 1 : 0;
+        else if (k == "estimator") { if (v < 0 || v > 3) return fail(t, MIPT_E_INVALID, "estimator must be 0 (reference), 1 (light sampling), 2 (VNDF + cosine lobes) or 3 (both)"); t->estimator = v; }
+        else if (k == "profile_levels") t->profileLevels = v ? 1 : 0;
+        else if (k == "integrator") { if (v != 0 && v != 1) return fail(t, MIPT_E_INVALID, "integrator must be 0 (wave stacks) or 1 (level queues)"); t->integrator = v; }
+        else if (k == "blocks_per_cu") { if (v < 1 || v > 32) return fail(t, MIPT_E_INVALID, "blocks_per_cu out of range"); t->blocksPerCU = v; }
+        else return fail(t, MIPT_E_INVALID, "unknown option " + k);
+        return MIPT_OK;
+    });
 }
 
 int mipt_set_tile_partition(mipt_tracer* t, uint32_t tile_rows, uint32_t n_parts, uint32_t part) {
-    if (!t) return MIPT_E_INVALID;
-    if (n_parts == 0 || part >= n_parts || (n_parts > 1 && tile_rows == 0)) return fail(t, MIPT_E_INVALID, "tile partition: need tile_rows >= 1 and part < n_parts");
-    t->tileRows = tile_rows; t->tileParts = n_parts; t->tilePart = part;
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t) return MIPT_E_INVALID;
+        if (n_parts == 0 || part >= n_parts || (n_parts > 1 && tile_rows == 0)) return fail(t, MIPT_E_INVALID, "tile partition: need tile_rows >= 1 and part < n_parts");
+        t->tileRows = tile_rows; t->tileParts = n_parts; t->tilePart = part;
+        return MIPT_OK;
+    });
 }
 
 int mipt_get_counters(mipt_tracer* t, mipt_counters* out) {
-    if (!t || !out) return MIPT_E_INVALID;
-    int rc = mipt_synchronize(t); if (rc) return rc;
-    unsigned long long rays = 0;
-    HIPCHK(t, hipMemcpy(&rays, t->stats, sizeof rays, hipMemcpyDeviceToHost));
-    unsigned long long shadow = 0;
-    HIPCHK(t, hipMemcpy(&shadow, t->stats + 38, sizeof shadow, hipMemcpyDeviceToHost));
-    out->rays = rays; out->frames = t->frames; out->kernel_ms = t->kernelMs; out->launches = t->launches; out->shadow_rays = shadow;
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t || !out) return MIPT_E_INVALID;
+        int rc = mipt_synchronize(t); if (rc) return rc;
+        unsigned long long rays = 0;
+        HIPCHK(t, hipMemcpy(&rays, t->stats, sizeof rays, hipMemcpyDeviceToHost));
+        unsigned long long shadow = 0;
+        HIPCHK(t, hipMemcpy(&shadow, t->stats + 38, sizeof shadow, hipMemcpyDeviceToHost));
+        out->rays = rays; out->frames = t->frames; out->kernel_ms = t->kernelMs; out->launches = t->launches; out->shadow_rays = shadow;
+        return MIPT_OK;
+    });
 }
 
 int mipt_reset_counters(mipt_tracer* t) {
-    if (!t) return MIPT_E_INVALID;
-    int rc = mipt_synchronize(t); if (rc) return rc;
-    HIPCHK(t, hipMemsetAsync(t->stats, 0, 40 * sizeof(unsigned long long), t->stream));
-    HIPCHK(t, hipStreamSynchronize(t->stream));
-    t->frames = 0; t->launches = 0; t->kernelMs = 0;
-    for (int i = 0; i < 32; i++) { t->levelMs[i] = 0; t->levelLaunches[i] = 0; }
-    t->accumulateMs = 0;
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t) return MIPT_E_INVALID;
+        int rc = mipt_synchronize(t); if (rc) return rc;
+        HIPCHK(t, hipMemsetAsync(t->stats, 0, 40 * sizeof(unsigned long long), t->stream));
+        HIPCHK(t, hipStreamSynchronize(t->stream));
+        t->frames = 0; t->launches = 0; t->kernelMs = 0;
+        for (int i = 0; i < 32; i++) { t->levelMs[i] = 0; t->levelLaunches[i] = 0; }
+        t->accumulateMs = 0;
+        return MIPT_OK;
+    });
 }
 
 int mipt_get_level_profile(mipt_tracer* t, mipt_level_profile* out) {
-    if (!t || !out) return MIPT_E_INVALID;
-    int rc = mipt_synchronize(t); if (rc) return rc;
-    unsigned long long st[40];
-    HIPCHK(t, hipMemcpy(st, t->stats, sizeof st, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 32; i++) { out->rays[i] = st[1 + i]; out->ms[i] = t->levelMs[i]; out->launches[i] = t->levelLaunches[i]; }
-    out->accumulate_ms = t->accumulateMs;
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t || !out) return MIPT_E_INVALID;
+        int rc = mipt_synchronize(t); if (rc) return rc;
+        unsigned long long st[40];
+        HIPCHK(t, hipMemcpy(st, t->stats, sizeof st, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 32; i++) { out->rays[i] = st[1 + i]; out->ms[i] = t->levelMs[i]; out->launches[i] = t->levelLaunches[i]; }
+        out->accumulate_ms = t->accumulateMs;
+        return MIPT_OK;
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -462,75 +513,77 @@ int mipt_get_level_profile(mipt_tracer* t, mipt_level_profile* out) {
 // reference's per-node cudaMemcpy walk (CUDATracer.hpp:99-129).
 // ---------------------------------------------------------------------------------------------------------------
 int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out) {
-    if (!d || !out) return MIPT_E_INVALID;
-    *out = nullptr;
-    if (t && use(t)) return MIPT_E_HIP;     // t == NULL: host-only scene (BVH build + mipt_scene_get_bvh, no upload)
-    std::vector<TriPos> tris;
-    std::vector<uint32_t> triMesh;
-    std::vector<float> shade;     // 12 per triangle
-    if (int rc = gather_geometry(t, d, tris, triMesh, shade)) return rc;
-    BvhParams bp;
-    bp.builder = d->bvhBuilder;
-    if (bp.builder != MIPT_BVH_SBVH && bp.builder != MIPT_BVH_MEDIAN) return fail(t, MIPT_E_INVALID, "unknown bvhBuilder");
-    if (d->maxLeafSize) bp.maxLeafSize = d->maxLeafSize;
-    if (d->splitAlpha > 0.f) bp.splitAlpha = d->splitAlpha;
-    // SAH triangle cost: measured optima are 1.5 for a scene traversed as BVH2 from LDS (a few dozen triangles) and 3.0
-    // for everything that ends up in 4-wide nodes (profiles/r1/exp_sah_tricost_leafsize.log, exp_sah_q4.log)
-    bp.triCost = d->sahTriCost > 0.f ? d->sahTriCost : (tris.size() <= 64 ? 1.5f : 3.0f);
-    bp.nodeWidth = d->nodeWidth;
-    if (bp.nodeWidth != 0 && bp.nodeWidth != 2 && bp.nodeWidth != 4) return fail(t, MIPT_E_INVALID, "nodeWidth must be 0, 2 or 4");
-    BvhOut bo;
-    const bool useCache = d->bvhCachePath && d->bvhCachePath[0];
-    const uint64_t cacheKey = useCache ? bvh_cache_key(tris, bp) : 0;
-    const bool cached = useCache && load_bvh_cache(d->bvhCachePath, cacheKey, (uint32_t)tris.size(), bp.nodeWidth, bo);
-    if (!cached) {
-        bo = BvhOut();
-        std::string berr = build_bvh(tris, bp, bo);
-        if (!berr.empty()) return fail(t, MIPT_E_LIMIT, "BVH build: " + berr);
-        if (useCache && !save_bvh_cache(d->bvhCachePath, cacheKey, (uint32_t)tris.size(), bo))
-            return fail(t, MIPT_E_INVALID, std::string("cannot write BVH cache ") + d->bvhCachePath);
-    }
+    return guarded(t, [&]() -> int {
+        if (!d || !out) return MIPT_E_INVALID;
+        *out = nullptr;
+        if (t && use(t)) return MIPT_E_HIP;     // t == NULL: host-only scene (BVH build + mipt_scene_get_bvh, no upload)
+        std::vector<TriPos> tris;
+        std::vector<uint32_t> triMesh;
+        std::vector<float> shade;     // 12 per triangle
+        if (int rc = gather_geometry(t, d, tris, triMesh, shade)) return rc;
+        BvhParams bp;
+        bp.builder = d->bvhBuilder;
+        if (bp.builder != MIPT_BVH_SBVH && bp.builder != MIPT_BVH_MEDIAN) return fail(t, MIPT_E_INVALID, "unknown bvhBuilder");
+        if (d->maxLeafSize) bp.maxLeafSize = d->maxLeafSize;
+        if (d->splitAlpha > 0.f) bp.splitAlpha = d->splitAlpha;
+        // SAH triangle cost: measured optima are 1.5 for a scene traversed as BVH2 from LDS (a few dozen triangles) and 3.0
+        // for everything that ends up in 4-wide nodes (profiles/r1/exp_sah_tricost_leafsize.log, exp_sah_q4.log)
+        bp.triCost = d->sahTriCost > 0.f ? d->sahTriCost : (tris.size() <= 64 ? 1.5f : 3.0f);
+        bp.nodeWidth = d->nodeWidth;
+        if (bp.nodeWidth != 0 && bp.nodeWidth != 2 && bp.nodeWidth != 4) return fail(t, MIPT_E_INVALID, "nodeWidth must be 0, 2 or 4");
+        BvhOut bo;
+        const bool useCache = d->bvhCachePath && d->bvhCachePath[0];
+        const uint64_t cacheKey = useCache ? bvh_cache_key(tris, bp) : 0;
+        const bool cached = useCache && load_bvh_cache(d->bvhCachePath, cacheKey, (uint32_t)tris.size(), bp.nodeWidth, bo);
+        if (!cached) {
+            bo = BvhOut();
+            std::string berr = build_bvh(tris, bp, bo);
+            if (!berr.empty()) return fail(t, MIPT_E_LIMIT, "BVH build: " + berr);
+            if (useCache && !save_bvh_cache(d->bvhCachePath, cacheKey, (uint32_t)tris.size(), bo))
+                return fail(t, MIPT_E_INVALID, std::string("cannot write BVH cache ") + d->bvhCachePath);
+        }
 
-    mipt_scene* s = new mipt_scene();
-    s->t = t; s->nMeshes = d->meshCnt; s->nTris = (uint32_t)tris.size(); s->bvhFromCache = cached; s->bvhWidth = bo.width;
-    s->hNodes = std::move(bo.nodes);
-    s->hRefTri = bo.refTri;
-    fill_refs(s->hRefTri, tris, triMesh, s->hRefs);
-    std::vector<float> mats; fill_materials(d, mats);
-    if (d->envMap && d->envW && d->envH) build_env_cdf(d->envMap, d->envW, d->envH, s->hEnvCdf);
-    const float emitScale = build_emitters(d, tris, triMesh, s->hEmitTri, s->hEmitCdf);
-    auto upload = [&](void** dst, const void* src, size_t bytes) -> bool {
-        if (bytes == 0) bytes = 16;
-        if (hipMalloc(dst, bytes) != hipSuccess) return false;
-        if (src && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return false;
-        return true;
-    };
-    if (shade.empty()) shade.resize(12, 0.f);
-    if (s->hRefs.empty()) s->hRefs.resize(12, 0.f);
-    if (t) {
-        bool ok = upload(&s->dNodes, s->hNodes.data(), s->hNodes.size() * 4) && upload(&s->dRefs, s->hRefs.data(), s->hRefs.size() * 4) &&
-                  upload(&s->dShade, shade.data(), shade.size() * 4) && upload(&s->dMats, mats.data(), mats.size() * 4);
-        if (ok && d->envMap && d->envW && d->envH) ok = upload(&s->dEnv, d->envMap, (size_t)d->envW * d->envH * 3 * 4);
-        if (ok && s->dEnv) ok = upload(&s->dEnvCdf, s->hEnvCdf.data(), s->hEnvCdf.size() * 4);
-        if (ok && !s->hEmitCdf.empty()) ok = upload(&s->dEmitTri, s->hEmitTri.data(), s->hEmitTri.size() * 4) && upload(&s->dEmitCdf, s->hEmitCdf.data(), s->hEmitCdf.size() * 4);
-        if (!ok) { mipt_scene_destroy(s); return fail(t, MIPT_E_NOMEM, "scene upload failed"); }
-    }
-    if (bo.refTri.empty()) s->hRefs.clear();
-    s->dev.nodes = (const float4*)s->dNodes; s->dev.refs = (const float4*)s->dRefs; s->dev.shade = (const float4*)s->dShade;
-    s->dev.mats = (const float4*)s->dMats; s->dev.env = (const float*)s->dEnv;
-    s->dev.envW = s->dEnv ? d->envW : 0; s->dev.envH = s->dEnv ? d->envH : 0;
-    s->dev.envCdf = (const float*)s->dEnvCdf;
-    s->dev.emitTri = (const float*)s->dEmitTri; s->dev.emitCdf = (const float*)s->dEmitCdf;
-    s->dev.nEmit = s->dEmitCdf ? (uint32_t)(s->hEmitCdf.size() - 1) : 0u; s->dev.emitScale = emitScale;
-    s->emitCap = s->dev.nEmit;
-    s->dev.neeScale = s->dEnv ? (float)(M_PI / 0.98 / ((double)d->envW * (double)d->envH)) : 0.f;
-    memcpy(s->dev.skyColor, d->sky.color, 12); memcpy(s->dev.skyDir, d->sky.dir, 12); s->dev.skyIntensity = d->sky.intensity;
-    s->dev.nNodes = (uint32_t)(s->hNodes.size() / 16); s->dev.nRefs = (uint32_t)bo.refTri.size();
-    s->dev.wide = bo.width == 4 ? 1u : 0u;
-    s->dev.stackNeed = bo.stackNeed;
-    if (t) hipDeviceSynchronize();
-    *out = s;
-    return MIPT_OK;
+        mipt_scene* s = new mipt_scene();
+        s->t = t; s->nMeshes = d->meshCnt; s->nTris = (uint32_t)tris.size(); s->bvhFromCache = cached; s->bvhWidth = bo.width;
+        s->hNodes = std::move(bo.nodes);
+        s->hRefTri = bo.refTri;
+        fill_refs(s->hRefTri, tris, triMesh, s->hRefs);
+        std::vector<float> mats; fill_materials(d, mats);
+        if (d->envMap && d->envW && d->envH) build_env_cdf(d->envMap, d->envW, d->envH, s->hEnvCdf);
+        const float emitScale = build_emitters(d, tris, triMesh, s->hEmitTri, s->hEmitCdf);
+        auto upload = [&](void** dst, const void* src, size_t bytes) -> bool {
+            if (bytes == 0) bytes = 16;
+            if (hipMalloc(dst, bytes) != hipSuccess) return false;
+            if (src && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return false;
+            return true;
+        };
+        if (shade.empty()) shade.resize(12, 0.f);
+        if (s->hRefs.empty()) s->hRefs.resize(12, 0.f);
+        if (t) {
+            bool ok = upload(&s->dNodes, s->hNodes.data(), s->hNodes.size() * 4) && upload(&s->dRefs, s->hRefs.data(), s->hRefs.size() * 4) &&
+                      upload(&s->dShade, shade.data(), shade.size() * 4) && upload(&s->dMats, mats.data(), mats.size() * 4);
+            if (ok && d->envMap && d->envW && d->envH) ok = upload(&s->dEnv, d->envMap, (size_t)d->envW * d->envH * 3 * 4);
+            if (ok && s->dEnv) ok = upload(&s->dEnvCdf, s->hEnvCdf.data(), s->hEnvCdf.size() * 4);
+            if (ok && !s->hEmitCdf.empty()) ok = upload(&s->dEmitTri, s->hEmitTri.data(), s->hEmitTri.size() * 4) && upload(&s->dEmitCdf, s->hEmitCdf.data(), s->hEmitCdf.size() * 4);
+            if (!ok) { mipt_scene_destroy(s); return fail(t, MIPT_E_NOMEM, "scene upload failed"); }
+        }
+        if (bo.refTri.empty()) s->hRefs.clear();
+        s->dev.nodes = (const float4*)s->dNodes; s->dev.refs = (const float4*)s->dRefs; s->dev.shade = (const float4*)s->dShade;
+        s->dev.mats = (const float4*)s->dMats; s->dev.env = (const float*)s->dEnv;
+        s->dev.envW = s->dEnv ? d->envW : 0; s->dev.envH = s->dEnv ? d->envH : 0;
+        s->dev.envCdf = (const float*)s->dEnvCdf;
+        s->dev.emitTri = (const float*)s->dEmitTri; s->dev.emitCdf = (const float*)s->dEmitCdf;
+        s->dev.nEmit = s->dEmitCdf ? (uint32_t)(s->hEmitCdf.size() - 1) : 0u; s->dev.emitScale = emitScale;
+        s->emitCap = s->dev.nEmit;
+        s->dev.neeScale = s->dEnv ? (float)(M_PI / 0.98 / ((double)d->envW * (double)d->envH)) : 0.f;
+        memcpy(s->dev.skyColor, d->sky.color, 12); memcpy(s->dev.skyDir, d->sky.dir, 12); s->dev.skyIntensity = d->sky.intensity;
+        s->dev.nNodes = (uint32_t)(s->hNodes.size() / 16); s->dev.nRefs = (uint32_t)bo.refTri.size();
+        s->dev.wide = bo.width == 4 ? 1u : 0u;
+        s->dev.stackNeed = bo.stackNeed;
+        if (t) hipDeviceSynchronize();
+        *out = s;
+        return MIPT_OK;
+    });
 }
 
 void mipt_scene_destroy(mipt_scene* s) {
@@ -549,57 +602,63 @@ void mipt_scene_destroy(mipt_scene* s) {
 
 // Moved vertices / edited materials on an uploaded scene (the use the reference's CUDAScene::GetMeshMutable,
 // CUDATracer.hpp:217-221, points at but never makes): the tree keeps its shape, boxes are re-fitted, the flat buffers are
-// overwritten in place.  Env map and sky are taken from the scene as created.
+// overwritten in place.  The sky light is taken from the desc too; the env map stays as created.
 int mipt_scene_refit(mipt_scene* s, const mipt_scene_desc* d) {
-    if (!s || !d) return MIPT_E_INVALID;
-    mipt_tracer* t = s->t;
-    if (t && use(t)) return MIPT_E_HIP;
-    if (d->meshCnt != s->nMeshes) return fail(t, MIPT_E_INVALID, "refit: mesh count differs from the scene's");
-    std::vector<TriPos> tris; std::vector<uint32_t> triMesh; std::vector<float> shade;
-    if (int rc = gather_geometry(t, d, tris, triMesh, shade)) return rc;
-    if (tris.size() != s->nTris) return fail(t, MIPT_E_INVALID, "refit: triangle count differs from the scene's");
-    if (s->nTris == 0) return MIPT_OK;
-    BvhOut bo; bo.nodes = s->hNodes; bo.refTri = s->hRefTri; bo.width = s->bvhWidth;
-    std::string err = refit_bvh(bo, tris);
-    if (!err.empty()) return fail(t, MIPT_E_LIMIT, "BVH refit: " + err);
-    std::vector<float> refs, mats, emitTri, emitCdf;
-    fill_refs(s->hRefTri, tris, triMesh, refs);
-    fill_materials(d, mats);
-    const float emitScale = build_emitters(d, tris, triMesh, emitTri, emitCdf);
-    if (t) {
-        // every frame in flight has been joined by use(); the stream of this tracer may still be running them
-        HIPCHK(t, hipStreamSynchronize(t->stream));
-        HIPCHK(t, hipMemcpy(s->dNodes, bo.nodes.data(), bo.nodes.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(t, hipMemcpy(s->dRefs, refs.data(), refs.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(t, hipMemcpy(s->dShade, shade.data(), shade.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(t, hipMemcpy(s->dMats, mats.data(), mats.size() * 4, hipMemcpyHostToDevice));
-        const size_t nEmit = emitCdf.empty() ? 0 : emitCdf.size() - 1;
-        if (nEmit > s->emitCap) {           // a material turned emissive: the emitter table grows
-            if (s->dEmitTri) HIPCHK(t, hipFree(s->dEmitTri));
-            if (s->dEmitCdf) HIPCHK(t, hipFree(s->dEmitCdf));
-            s->dEmitTri = s->dEmitCdf = nullptr; s->emitCap = 0;
-            HIPCHK(t, hipMalloc(&s->dEmitTri, nEmit * 15 * 4));
-            HIPCHK(t, hipMalloc(&s->dEmitCdf, (nEmit + 1) * 4));
-            s->emitCap = nEmit;
+    return guarded(nullptr, [&]() -> int {
+        if (!s || !d) return MIPT_E_INVALID;
+        mipt_tracer* t = s->t;
+        if (t && use(t)) return MIPT_E_HIP;
+        if (d->meshCnt != s->nMeshes) return fail(t, MIPT_E_INVALID, "refit: mesh count differs from the scene's");
+        std::vector<TriPos> tris; std::vector<uint32_t> triMesh; std::vector<float> shade;
+        if (int rc = gather_geometry(t, d, tris, triMesh, shade)) return rc;
+        if (tris.size() != s->nTris) return fail(t, MIPT_E_INVALID, "refit: triangle count differs from the scene's");
+        if (s->nTris == 0) return MIPT_OK;
+        BvhOut bo; bo.nodes = s->hNodes; bo.refTri = s->hRefTri; bo.width = s->bvhWidth;
+        std::string err = refit_bvh(bo, tris);
+        if (!err.empty()) return fail(t, MIPT_E_LIMIT, "BVH refit: " + err);
+        std::vector<float> refs, mats, emitTri, emitCdf;
+        fill_refs(s->hRefTri, tris, triMesh, refs);
+        fill_materials(d, mats);
+        const float emitScale = build_emitters(d, tris, triMesh, emitTri, emitCdf);
+        if (t) {
+            // every frame in flight has been joined by use(); the stream of this tracer may still be running them
+            HIPCHK(t, hipStreamSynchronize(t->stream));
+            HIPCHK(t, hipMemcpy(s->dNodes, bo.nodes.data(), bo.nodes.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(t, hipMemcpy(s->dRefs, refs.data(), refs.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(t, hipMemcpy(s->dShade, shade.data(), shade.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(t, hipMemcpy(s->dMats, mats.data(), mats.size() * 4, hipMemcpyHostToDevice));
+            const size_t nEmit = emitCdf.empty() ? 0 : emitCdf.size() - 1;
+            if (nEmit > s->emitCap) {           // a material turned emissive: the emitter table grows
+                if (s->dEmitTri) HIPCHK(t, hipFree(s->dEmitTri));
+                if (s->dEmitCdf) HIPCHK(t, hipFree(s->dEmitCdf));
+                s->dEmitTri = s->dEmitCdf = nullptr; s->emitCap = 0;
+                HIPCHK(t, hipMalloc(&s->dEmitTri, nEmit * 15 * 4));
+                HIPCHK(t, hipMalloc(&s->dEmitCdf, (nEmit + 1) * 4));
+                s->emitCap = nEmit;
+            }
+            if (nEmit) {
+                HIPCHK(t, hipMemcpy(s->dEmitTri, emitTri.data(), emitTri.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(t, hipMemcpy(s->dEmitCdf, emitCdf.data(), emitCdf.size() * 4, hipMemcpyHostToDevice));
+            }
+            s->dev.emitTri = (const float*)s->dEmitTri; s->dev.emitCdf = (const float*)s->dEmitCdf;
+            s->dev.nEmit = (uint32_t)nEmit; s->dev.emitScale = emitScale;
         }
-        if (nEmit) {
-            HIPCHK(t, hipMemcpy(s->dEmitTri, emitTri.data(), emitTri.size() * 4, hipMemcpyHostToDevice));
-            HIPCHK(t, hipMemcpy(s->dEmitCdf, emitCdf.data(), emitCdf.size() * 4, hipMemcpyHostToDevice));
-        }
-        s->dev.emitTri = (const float*)s->dEmitTri; s->dev.emitCdf = (const float*)s->dEmitCdf;
-        s->dev.nEmit = (uint32_t)nEmit; s->dev.emitScale = emitScale;
-    }
-    s->hNodes.swap(bo.nodes); s->hRefs.swap(refs); s->hEmitTri.swap(emitTri); s->hEmitCdf.swap(emitCdf);
-    return MIPT_OK;
+        // the analytic sky is a launch parameter, not a buffer: taken from the desc as well (the env map stays)
+        memcpy(s->dev.skyColor, d->sky.color, 12); memcpy(s->dev.skyDir, d->sky.dir, 12); s->dev.skyIntensity = d->sky.intensity;
+        s->hNodes.swap(bo.nodes); s->hRefs.swap(refs); s->hEmitTri.swap(emitTri); s->hEmitCdf.swap(emitCdf);
+        return MIPT_OK;
+    });
 }
 
 int mipt_scene_get_bvh(const mipt_scene* s, float* nodes, uint32_t* n_nodes, float* refs, uint32_t* n_refs) {
-    if (!s) return MIPT_E_INVALID;
-    if (n_nodes) *n_nodes = (uint32_t)(s->hNodes.size() / 16);
-    if (n_refs) *n_refs = (uint32_t)(s->hRefs.size() / 12);
-    if (nodes) memcpy(nodes, s->hNodes.data(), s->hNodes.size() * 4);
-    if (refs) memcpy(refs, s->hRefs.data(), s->hRefs.size() * 4);
-    return MIPT_OK;
+    return guarded(nullptr, [&]() -> int {
+        if (!s) return MIPT_E_INVALID;
+        if (n_nodes) *n_nodes = (uint32_t)(s->hNodes.size() / 16);
+        if (n_refs) *n_refs = (uint32_t)(s->hRefs.size() / 12);
+        if (nodes) memcpy(nodes, s->hNodes.data(), s->hNodes.size() * 4);
+        if (refs) memcpy(refs, s->hRefs.data(), s->hRefs.size() * 4);
+        return MIPT_OK;
+    });
 }
 uint32_t mipt_scene_triangle_count(const mipt_scene* s) { return s ? s->nTris : 0; }
 uint32_t mipt_scene_bvh_width(const mipt_scene* s) { return s ? s->bvhWidth : 0; }
@@ -621,203 +680,226 @@ int mipt_scene_bvh_was_cached(const mipt_scene* s) { return s && s->bvhFromCache
 // ---------------------------------------------------------------------------------------------------------------
 int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_t first_frame, uint32_t n_frames,
                 uint32_t frame_stride, int sum_mode, float* acc_dev, unsigned char* ldr_dev) {
-    if (!t || !sc || !st || !acc_dev) return fail(t, MIPT_E_INVALID, "null argument");
-    if (sc->t != t) return fail(t, MIPT_E_INVALID, "scene belongs to another tracer");
-    if (use_device(t)) return MIPT_E_HIP;
-    const uint32_t W = st->viewportWidth, H = st->viewportHeight, D = st->maxDepth;
-    if (!W || !H) return fail(t, MIPT_E_INVALID, "empty viewport");
-    if ((uint64_t)W * H >= (1ull << 31)) return fail(t, MIPT_E_LIMIT, "viewport too large");
-    if (D > 30) return fail(t, MIPT_E_LIMIT, "maxDepth > 30 (node ids are 32-bit)");
-    if (t->rngMode == MIPT_RNG_DFS && D > 16) return fail(t, MIPT_E_LIMIT, "rng_mode dfs supports maxDepth <= 16");
-    if (frame_stride == 0) frame_stride = 1;
-    const uint32_t npix = W * H;
-    // env-map importance sampling: wave-stack integrator with node-keyed streams only, and only with an env map to sample
-    const bool nee = t->estimator == 1 || t->estimator == 3;
-    if (nee && (t->rngMode != MIPT_RNG_NODE || t->integrator != 0)) return fail(t, MIPT_E_INVALID, "estimators 1 and 3 need integrator 0 and rng_mode node");
-    if (nee && !sc->dev.envCdf && !sc->dev.nEmit) return fail(t, MIPT_E_INVALID, "estimators 1 and 3 need a scene with an environment map or emissive triangles");
-    if (nee && npix >= (1u << 29)) return fail(t, MIPT_E_LIMIT, "viewport too large for estimator 1");
-    if (t->estimator >= 2 && (t->rngMode != MIPT_RNG_NODE || t->integrator != 0)) return fail(t, MIPT_E_INVALID, "estimator 2 needs integrator 0 and rng_mode node");
+    return guarded(t, [&]() -> int {
+        if (!t || !sc || !st || !acc_dev) return fail(t, MIPT_E_INVALID, "null argument");
+        if (sc->t != t) return fail(t, MIPT_E_INVALID, "scene belongs to another tracer");
+        if (use_device(t)) return MIPT_E_HIP;
+        const uint32_t W = st->viewportWidth, H = st->viewportHeight, D = st->maxDepth;
+        if (!W || !H) return fail(t, MIPT_E_INVALID, "empty viewport");
+        if ((uint64_t)W * H >= (1ull << 31)) return fail(t, MIPT_E_LIMIT, "viewport too large");
+        if (D > 30) return fail(t, MIPT_E_LIMIT, "maxDepth > 30 (node ids are 32-bit)");
+        if (t->rngMode == MIPT_RNG_DFS && D > 16) return fail(t, MIPT_E_LIMIT, "rng_mode dfs supports maxDepth <= 16");
+        if (frame_stride == 0) frame_stride = 1;
+        const uint32_t npix = W * H;
+        // env-map importance sampling: wave-stack integrator with node-keyed streams only, and only with an env map to sample
+        const bool nee = t->estimator == 1 || t->estimator == 3;
+        if (nee && (t->rngMode != MIPT_RNG_NODE || t->integrator != 0)) return fail(t, MIPT_E_INVALID, "estimators 1 and 3 need integrator 0 and rng_mode node");
+        if (nee && !sc->dev.envCdf && !sc->dev.nEmit) return fail(t, MIPT_E_INVALID, "estimators 1 and 3 need a scene with an environment map or emissive triangles");
+        if (nee && npix >= (1u << 29)) return fail(t, MIPT_E_LIMIT, "viewport too large for estimator 1");
+        if (t->estimator >= 2 && (t->rngMode != MIPT_RNG_NODE || t->integrator != 0)) return fail(t, MIPT_E_INVALID, "estimator 2 needs integrator 0 and rng_mode node");
 
-    if (t->samplePixels < npix) {
-        if (t->sample) hipFree(t->sample);
-        t->sample = nullptr; t->samplePixels = 0;
-        HIPCHK(t, hipMalloc((void**)&t->sample, (size_t)npix * 16));
-        t->samplePixels = npix;
-    }
-    if (t->countPixelRays && t->pixelRaysCap < npix) {
-        if (t->pixelRays) hipFree(t->pixelRays);
-        t->pixelRays = nullptr; t->pixelRaysCap = 0;
-        HIPCHK(t, hipMalloc((void**)&t->pixelRays, (size_t)npix * 4));
-        t->pixelRaysCap = npix;
-    }
-    const int persistentBlocks = t->numCU * (int)t->blocksPerCU;
-    uint32_t tile = npix;
-    uint32_t wcap = 0;
-    // Frame pipeline.  A wave of the persistent kernel cannot give work away, so a frame ends with a tail in which the
-    // waves holding the heaviest pixels finish alone (measured: 10-20 % of a 1080p frame, scripts/tail_profile.py).
-    // Consecutive frames therefore alternate between two streams with their own wave stacks and pixel counter, writing
-    // into a ring of sample buffers: the next frame's blocks move onto the CUs as the previous frame's blocks retire.
-    // The folds into the caller's buffers go, in frame order, onto a third, high-priority stream (behind a persistent
-    // kernel's resident waves a normal-priority fold starves for milliseconds), so the running mean is folded in order
-    // and no integrator launch ever queues behind a fold.
-    // Off for a caller-supplied stream (the caller expects everything in order there), per-pixel ray counting, and
-    // the other integrators.
-    // row-tile partition: this handle renders tiles part, part + parts, ... of tile_rows rows each
-    Band band{ 0u, 1u, 0u };
-    uint32_t npixPart = npix;
-    if (t->tileParts > 1) {
-        if (t->rngMode != MIPT_RNG_NODE || t->integrator != 0 || D < 1) return fail(t, MIPT_E_INVALID, "a tile partition needs integrator 0, rng_mode node and maxDepth >= 1");
-        const uint32_t W = st->viewportWidth, H = st->viewportHeight;
-        if ((uint64_t)t->tileRows * W >= (1ull << 31)) return fail(t, MIPT_E_LIMIT, "tile too large");
-        const uint32_t nTiles = (H + t->tileRows - 1) / t->tileRows;
-        uint64_t rows = 0;
-        for (uint32_t k = t->tilePart; k < nTiles; k += t->tileParts) rows += std::min(t->tileRows, H - k * t->tileRows);
-        band = Band{ t->tileRows * W, t->tileParts, t->tilePart };
-        npixPart = (uint32_t)(rows * W);
-    }
-    const bool pipe = t->pipelineFrames && t->stream == t->own && !t->countPixelRays && t->rngMode == MIPT_RNG_NODE && t->integrator == 0 && D >= 1;
-    if (!pipe) join_aux(t);
-    if (t->rngMode == MIPT_RNG_DFS) {
-        // depth-first integrator: no queues
-    } else if (t->integrator == 0) {
-        // persistent wave stacks: 256 entries per recursion level per wave (see k_wavestack), independent of the viewport
-        wcap = (nee ? 512u : 256u) * std::max<uint32_t>(D, 1u) + 256u;      // estimator 1: up to four rays per hit
-        const size_t need = (size_t)persistentBlocks * 4 * wcap;
-        if (t->wstackEntries < need) {
-            free_queue(t->wstack); t->wstackEntries = 0;
-            HIPCHK(t, hipMalloc((void**)&t->wstack.a, need * sizeof(float4)));
-            HIPCHK(t, hipMalloc((void**)&t->wstack.b, need * sizeof(float4)));
-            HIPCHK(t, hipMalloc((void**)&t->wstack.c, need * sizeof(float4)));
-            t->wstackEntries = need;
+        if (t->samplePixels < npix) {
+            if (t->sample) hipFree(t->sample);
+            t->sample = nullptr; t->samplePixels = 0;
+            HIPCHK(t, hipMalloc((void**)&t->sample, (size_t)npix * 16));
+            t->samplePixels = npix;
+            t->slotDirty[0] = npix;
         }
-        if (pipe) {
-            if (t->wstack2Entries < need) {
-                free_queue(t->wstack2); t->wstack2Entries = 0;
-                HIPCHK(t, hipMalloc((void**)&t->wstack2.a, need * sizeof(float4)));
-                HIPCHK(t, hipMalloc((void**)&t->wstack2.b, need * sizeof(float4)));
-                HIPCHK(t, hipMalloc((void**)&t->wstack2.c, need * sizeof(float4)));
-                t->wstack2Entries = need;
-            }
-            if (t->ringPixels < npix) {
-                for (int i = 1; i < mipt_tracer::kRing; i++) {
-                    if (t->ring[i]) hipFree(t->ring[i]);
-                    t->ring[i] = nullptr;
-                }
-                t->ringPixels = 0;
-                for (int i = 1; i < mipt_tracer::kRing; i++) HIPCHK(t, hipMalloc((void**)&t->ring[i], (size_t)npix * 16));
-                t->ringPixels = npix;
-            }
-            if (!t->counts2) HIPCHK(t, hipMalloc((void**)&t->counts2, 64 * sizeof(uint32_t)));
+        if (t->countPixelRays && t->pixelRaysCap < npix) {
+            if (t->pixelRays) hipFree(t->pixelRays);
+            t->pixelRays = nullptr; t->pixelRaysCap = 0;
+            HIPCHK(t, hipMalloc((void**)&t->pixelRays, (size_t)npix * 4));
+            t->pixelRaysCap = npix;
         }
-    } else if (D >= 2) {
-    // tile size: rays at level k <= tile * 2^k; the two ping-pong queues hold the largest odd / even level
-        uint64_t maxEntries = (uint64_t)t->queueBudgetMB * 1024 * 1024 / 48;
-        uint64_t perPixel = (1ull << (D - 1)) + (D >= 3 ? (1ull << (D - 2)) : 0);
-        uint64_t fit = maxEntries / perPixel;
-        if (t->tilePixels > 0) fit = (uint64_t)t->tilePixels;
-        if (fit < 64) return fail(t, MIPT_E_LIMIT, "queue budget too small for this maxDepth");
-        if (fit < tile) tile = (uint32_t)fit;
-        if (tile >= 256) tile &= ~255u;
-        if (((uint64_t)tile << (D - 1)) >= (1ull << 32)) return fail(t, MIPT_E_LIMIT, "tile * 2^(maxDepth-1) exceeds 32-bit queue indices");
-        uint32_t oddMax = ((D - 1) & 1) ? (D - 1) : (D - 2);          // largest odd level <= D-1 (>= 1)
-        uint32_t evenMax = ((D - 1) & 1) ? (D - 2) : (D - 1);         // largest even level <= D-1 (may be 0 -> unused)
-        int rc = ensure_queue(t, 1, (size_t)tile << oddMax); if (rc) return rc;
-        if (evenMax >= 2) { rc = ensure_queue(t, 0, (size_t)tile << evenMax); if (rc) return rc; }
-    }
-
-    if (pipe && t->mainTouched) {       // aux / fold start after whatever else the caller queued on the tracer's stream (clears, uploads ...)
-        HIPCHK(t, hipEventRecord(t->joinEv, t->stream));
-        HIPCHK(t, hipStreamWaitEvent(t->aux, t->joinEv, 0));
-        HIPCHK(t, hipStreamWaitEvent(t->fold, t->joinEv, 0));
-        t->mainTouched = false;
-    }
-    t->ring[0] = t->sample;
-    for (uint32_t fi = 0; fi < n_frames; fi++) {
-        const uint32_t frame = first_frame + fi * frame_stride;
-        const int set = pipe ? (int)(t->flip & 1u) : 0;
-        const int slot = pipe ? (int)(t->flip % (uint32_t)mipt_tracer::kRing) : 0;
-        if (pipe) t->flip++;
-        hipStream_t S = set ? t->aux : t->stream;
-        float* sample = t->ring[slot];
-        uint32_t* counts = set ? t->counts2 : t->counts;
-        if (pipe) t->pipeBusy = true;
-        t->lastSlot = slot;
-        if (pipe && t->foldValid[slot]) HIPCHK(t, hipStreamWaitEvent(S, t->foldEv[slot], 0));      // the slot's previous frame has been folded
-        HIPCHK(t, hipMemsetAsync(sample, 0, (size_t)npix * 16, S));
-        if (t->countPixelRays) HIPCHK(t, hipMemsetAsync(t->pixelRays, 0, (size_t)npix * 4, S));
-        LevelArgs A;
-        A.S = sc->dev; A.F = make_frame(*st, frame);
-        A.sample = sample; A.pixelRays = t->countPixelRays ? t->pixelRays : nullptr; A.stats = t->stats;
-        hipEvent_t ka, kb;                  // integrator kernel time of this frame (they overlap across frames when pipelined)
-        HIPCHK(t, hipEventCreate(&ka)); HIPCHK(t, hipEventCreate(&kb));
+        const int persistentBlocks = t->numCU * (int)t->blocksPerCU;
+        uint32_t tile = npix;
+        uint32_t wcap = 0;
+        // Frame pipeline.  A wave of the persistent kernel cannot give work away, so a frame ends with a tail in which the
+        // waves holding the heaviest pixels finish alone (measured: 10-20 % of a 1080p frame, scripts/tail_profile.py).
+        // Consecutive frames therefore alternate between two streams with their own wave stacks and pixel counter, writing
+        // into a ring of sample buffers: the next frame's blocks move onto the CUs as the previous frame's blocks retire.
+        // The folds into the caller's buffers go, in frame order, onto a third, high-priority stream (behind a persistent
+        // kernel's resident waves a normal-priority fold starves for milliseconds), so the running mean is folded in order
+        // and no integrator launch ever queues behind a fold.
+        // Off for a caller-supplied stream (the caller expects everything in order there), per-pixel ray counting, and
+        // the other integrators.
+        // row-tile partition: this handle renders tiles part, part + parts, ... of tile_rows rows each
+        Band band{ 0u, 1u, 0u };
+        uint32_t npixPart = npix;
+        if (t->tileParts > 1) {
+            if (t->rngMode != MIPT_RNG_NODE || t->integrator != 0 || D < 1) return fail(t, MIPT_E_INVALID, "a tile partition needs integrator 0, rng_mode node and maxDepth >= 1");
+            const uint32_t W = st->viewportWidth, H = st->viewportHeight;
+            if ((uint64_t)t->tileRows * W >= (1ull << 31)) return fail(t, MIPT_E_LIMIT, "tile too large");
+            const uint32_t nTiles = (H + t->tileRows - 1) / t->tileRows;
+            uint64_t rows = 0;
+            for (uint32_t k = t->tilePart; k < nTiles; k += t->tileParts) rows += std::min(t->tileRows, H - k * t->tileRows);
+            band = Band{ t->tileRows * W, t->tileParts, t->tilePart };
+            npixPart = (uint32_t)(rows * W);
+        }
+        const bool pipe = t->pipelineFrames && t->stream == t->own && !t->countPixelRays && t->rngMode == MIPT_RNG_NODE && t->integrator == 0 && D >= 1;
+        if (!pipe) join_aux(t);
         if (t->rngMode == MIPT_RNG_DFS) {
-            DfsArgs DA;
-            DA.S = sc->dev; DA.F = A.F; DA.sample = A.sample; DA.pixelRays = A.pixelRays; DA.stats = t->stats; DA.pix0 = 0; DA.npix = npix;
-            mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
-            if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, S)); }
-            HIPCHK(t, hipEventRecord(ka, S));
-            launch_dfs(DA, 0, S);
-            HIPCHK(t, hipEventRecord(kb, S));
-            if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, S)); t->levelPending.push_back(le); }
-            t->launches++;
-        } else if (t->integrator == 0 && D >= 1) {
-            HIPCHK(t, hipMemsetAsync(counts, 0, 64 * sizeof(uint32_t), S));
-            StackArgs SA;
-            SA.S = sc->dev; SA.F = A.F; SA.stack = set ? t->wstack2 : t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes;
-            // min_descend_lanes auto: 8 for an LDS-resident scene, 24 otherwise (measured optima, profiles/r1/exp_min_descend.log)
-            const bool ldsScene = wavestack_scene_in_lds(sc->dev);
-            SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (ldsScene ? 8 : 24));
-            SA.pixCounter = counts; SA.nee = (uint32_t)t->estimator;
-            // xcd_bands auto: on when nodes + references exceed one XCD's 4 MiB L2 or the frame has 4 Mi pixels or more.
-            // Eight counters also spread the claims (one word sustains ~90 atomics/us, MI355X_MICROARCH.md; frames of cheap
-            // pixels come close to that), which fits the gain growing as the pixels get cheaper: 4K grids
-            // of 1.8 k ... 10 M triangles +32 ... +4 %, Cornell / Default at 4K +0.5 %; at 1080p the cache-resident
-            // scenes lose to a longer tail (Cornell -2 %, Default -0.5 %) and keep one counter (profiles/r1/exp_xcd_bands.log)
-            const size_t workingSet = (size_t)sc->dev.nNodes * 64 + (size_t)sc->dev.nRefs * 48;
-            SA.xcdBands = (uint32_t)(t->xcdBands >= 0 ? t->xcdBands : ((workingSet > (4u << 20) || npixPart >= (1u << 22)) ? 1 : 0));
-            SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npixPart; SA.band = band;
-            mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
-            if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, S)); }
-            HIPCHK(t, hipEventRecord(ka, S));
-            if (npixPart) launch_wavestack(SA, std::min<int>((int)((npixPart + 255) / 256), persistentBlocks), S);
-            HIPCHK(t, hipEventRecord(kb, S));
-            if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, S)); t->levelPending.push_back(le); }
-            t->launches++;
-        } else {
-            HIPCHK(t, hipEventRecord(ka, S));
-            for (uint32_t p0 = 0; p0 < npix; p0 += tile) {
-                const uint32_t np = std::min(tile, npix - p0);
-                HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), S));
-                A.pix0 = p0; A.npix = np;
-                for (uint32_t k = 0; k < D; k++) {
-                    A.level = k;
-                    A.qin = t->q[k & 1]; A.qout = t->q[(k + 1) & 1];
-                    A.inCount = t->counts + k; A.outCount = t->counts + k + 1;
-                    int blocks = k == 0 ? std::min<int>((int)((np + 255) / 256), persistentBlocks) : persistentBlocks;
-                    mipt_tracer::LevelEv le{ nullptr, nullptr, (int)k };
-                    if (t->profileLevels) { HIPCHK(t, hipEventCreate(&le.a)); HIPCHK(t, hipEventCreate(&le.b)); HIPCHK(t, hipEventRecord(le.a, S)); }
-                    launch_level(A, k == 0, blocks, S);
-                    if (t->profileLevels) { HIPCHK(t, hipEventRecord(le.b, S)); t->levelPending.push_back(le); }
-                    t->launches++;
-                }
+            // depth-first integrator: no queues
+        } else if (t->integrator == 0) {
+            // persistent wave stacks: 256 entries per recursion level per wave (see k_wavestack), independent of the viewport
+            wcap = (nee ? 512u : 256u) * std::max<uint32_t>(D, 1u) + 256u;      // estimator 1: up to four rays per hit
+            const size_t need = (size_t)persistentBlocks * 4 * wcap;
+            if (t->wstackEntries < need) {
+                free_queue(t->wstack); t->wstackEntries = 0;
+                HIPCHK(t, hipMalloc((void**)&t->wstack.a, need * sizeof(float4)));
+                HIPCHK(t, hipMalloc((void**)&t->wstack.b, need * sizeof(float4)));
+                HIPCHK(t, hipMalloc((void**)&t->wstack.c, need * sizeof(float4)));
+                t->wstackEntries = need;
             }
-            HIPCHK(t, hipEventRecord(kb, S));
+            if (pipe) {
+                if (t->wstack2Entries < need) {
+                    free_queue(t->wstack2); t->wstack2Entries = 0;
+                    HIPCHK(t, hipMalloc((void**)&t->wstack2.a, need * sizeof(float4)));
+                    HIPCHK(t, hipMalloc((void**)&t->wstack2.b, need * sizeof(float4)));
+                    HIPCHK(t, hipMalloc((void**)&t->wstack2.c, need * sizeof(float4)));
+                    t->wstack2Entries = need;
+                }
+                if (t->ringPixels < npix) {
+                    for (int i = 1; i < mipt_tracer::kRing; i++) {
+                        if (t->ring[i]) hipFree(t->ring[i]);
+                        t->ring[i] = nullptr;
+                    }
+                    t->ringPixels = 0;
+                    for (int i = 1; i < mipt_tracer::kRing; i++) { HIPCHK(t, hipMalloc((void**)&t->ring[i], (size_t)npix * 16)); t->slotDirty[i] = npix; }
+                    t->ringPixels = npix;
+                }
+                if (!t->counts2) HIPCHK(t, hipMalloc((void**)&t->counts2, 64 * sizeof(uint32_t)));
+            }
+        } else if (D >= 2) {
+        // tile size: rays at level k <= tile * 2^k; the two ping-pong queues hold the largest odd / even level
+            uint64_t maxEntries = (uint64_t)t->queueBudgetMB * 1024 * 1024 / 48;
+            uint64_t perPixel = (1ull << (D - 1)) + (D >= 3 ? (1ull << (D - 2)) : 0);
+            uint64_t fit = maxEntries / perPixel;
+            if (t->tilePixels > 0) fit = (uint64_t)t->tilePixels;
+            if (fit < 64) return fail(t, MIPT_E_LIMIT, "queue budget too small for this maxDepth");
+            if (fit < tile) tile = (uint32_t)fit;
+            if (tile >= 256) tile &= ~255u;
+            if (((uint64_t)tile << (D - 1)) >= (1ull << 32)) return fail(t, MIPT_E_LIMIT, "tile * 2^(maxDepth-1) exceeds 32-bit queue indices");
+            uint32_t oddMax = ((D - 1) & 1) ? (D - 1) : (D - 2);          // largest odd level <= D-1 (>= 1)
+            uint32_t evenMax = ((D - 1) & 1) ? (D - 2) : (D - 1);         // largest even level <= D-1 (may be 0 -> unused)
+            int rc = ensure_queue(t, 1, (size_t)tile << oddMax); if (rc) return rc;
+            if (evenMax >= 2) { rc = ensure_queue(t, 0, (size_t)tile << evenMax); if (rc) return rc; }
         }
-        t->pending.emplace_back(ka, kb);
-        // fold into the caller's buffers, in frame order
-        hipStream_t F = pipe ? t->fold : S;
-        if (pipe) { HIPCHK(t, hipEventRecord(t->kernEv[slot], S)); HIPCHK(t, hipStreamWaitEvent(F, t->kernEv[slot], 0)); }
-        const float weight = (float)(1.0 / (frame + 1.0));       // CUDATracerProg.cu:878
-        mipt_tracer::LevelEv ae{ nullptr, nullptr, -1 };
-        if (t->profileLevels) { HIPCHK(t, hipEventCreate(&ae.a)); HIPCHK(t, hipEventCreate(&ae.b)); HIPCHK(t, hipEventRecord(ae.a, F)); }
-        launch_accumulate(sample, acc_dev, ldr_dev, weight, sum_mode, band, 0, npixPart, F);
-        if (t->profileLevels) { HIPCHK(t, hipEventRecord(ae.b, F)); t->levelPending.push_back(ae); }
-        if (pipe) { HIPCHK(t, hipEventRecord(t->foldEv[slot], F)); t->foldValid[slot] = true; }
-        t->frames++;
-    }
-    HIPCHK(t, hipGetLastError());
-    if (t->pending.size() > 256 || t->levelPending.size() > 4096) resolve_events(t);
-    return MIPT_OK;
+
+        if (pipe && t->mainTouched) {       // aux / fold start after whatever else the caller queued on the tracer's stream (clears, uploads ...)
+            HIPCHK(t, hipEventRecord(t->joinEv, t->stream));
+            HIPCHK(t, hipStreamWaitEvent(t->aux, t->joinEv, 0));
+            HIPCHK(t, hipStreamWaitEvent(t->fold, t->joinEv, 0));
+            t->mainTouched = false;
+        }
+        t->ring[0] = t->sample;
+        // Per-frame side work.  The sample buffer of a frame must start at zero (the integrator adds into
+        // it).  A pipelined fold now clears its slot right after reading it, so the 16 B/pixel clear per frame is gone; only a
+        // slot that was left standing (option keep_sample, or a frame of one of the unpipelined paths whose sample the
+        // caller may still read through mipt_last_sample) is cleared before its next use.  In sum mode without an LDR
+        // target the integrator adds straight into the caller's accumulation buffer: no sample buffer, no fold.
+        const bool direct = sum_mode && !ldr_dev && !t->countPixelRays && t->rngMode == MIPT_RNG_NODE && t->integrator == 0 && D >= 1;
+        for (uint32_t fi = 0; fi < n_frames; fi++) {
+            const uint32_t frame = first_frame + fi * frame_stride;
+            const int set = pipe ? (int)(t->flip & 1u) : 0;
+            const int slot = (pipe && !direct) ? (int)(t->flip % (uint32_t)mipt_tracer::kRing) : 0;
+            if (pipe) t->flip++;
+            hipStream_t S = set ? t->aux : t->stream;
+            float* sample = direct ? acc_dev : t->ring[slot];
+            uint32_t* counts = set ? t->counts2 : t->counts;
+            if (pipe) t->pipeBusy = true;
+            const bool zeroAfter = pipe && !direct && !t->keepSample;
+            if (!direct) {
+                t->lastSlot = slot;
+                if (pipe && t->foldValid[slot]) HIPCHK(t, hipStreamWaitEvent(S, t->foldEv[slot], 0));      // the slot's previous frame has been folded
+                if (t->slotDirty[slot]) HIPCHK(t, hipMemsetAsync(sample, 0, t->slotDirty[slot] * 16, S));
+                t->slotDirty[slot] = zeroAfter ? 0 : npix;
+            }
+            t->sampleConsumed = zeroAfter || direct;
+            if (t->countPixelRays) HIPCHK(t, hipMemsetAsync(t->pixelRays, 0, (size_t)npix * 4, S));
+            LevelArgs A;
+            A.S = sc->dev; A.F = make_frame(*st, frame);
+            A.sample = sample; A.pixelRays = t->countPixelRays ? t->pixelRays : nullptr; A.stats = t->stats;
+            hipEvent_t ka = take_event(t), kb = take_event(t);      // integrator kernel time of this frame (they overlap across frames when pipelined)
+            if (!ka || !kb) { give_event(t, ka); give_event(t, kb); return fail(t, MIPT_E_HIP, "hipEventCreate failed"); }
+            t->pending.emplace_back(ka, kb);                        // from here on resolve_events returns them to the pool
+            auto level_events = [&](mipt_tracer::LevelEv& le, hipStream_t on) -> bool {
+                le.a = take_event(t); le.b = take_event(t);
+                if (!le.a || !le.b) { give_event(t, le.a); give_event(t, le.b); le.a = le.b = nullptr; return false; }
+                t->levelPending.push_back(le);
+                return hipEventRecord(le.a, on) == hipSuccess;
+            };
+            if (t->rngMode == MIPT_RNG_DFS) {
+                DfsArgs DA;
+                DA.S = sc->dev; DA.F = A.F; DA.sample = A.sample; DA.pixelRays = A.pixelRays; DA.stats = t->stats; DA.pix0 = 0; DA.npix = npix;
+                mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
+                const bool prof = t->profileLevels && level_events(le, S);
+                HIPCHK(t, hipEventRecord(ka, S));
+                launch_dfs(DA, 0, S);
+                HIPCHK(t, hipEventRecord(kb, S));
+                if (prof) HIPCHK(t, hipEventRecord(le.b, S));
+                t->launches++;
+            } else if (t->integrator == 0 && D >= 1) {
+                HIPCHK(t, hipMemsetAsync(counts, 0, 64 * sizeof(uint32_t), S));
+                StackArgs SA;
+                SA.S = sc->dev; SA.F = A.F; SA.stack = set ? t->wstack2 : t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes;
+                // min_descend_lanes auto: 8 for an LDS-resident scene, 24 otherwise (measured optima, profiles/r1/exp_min_descend.log)
+                const bool ldsScene = wavestack_scene_in_lds(sc->dev);
+                SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (ldsScene ? 8 : 24));
+                SA.pixCounter = counts; SA.nee = (uint32_t)t->estimator;
+                // xcd_bands auto: on when nodes + references exceed one XCD's 4 MiB L2 or the frame has 4 Mi pixels or more.
+                // Eight counters also spread the claims (one word sustains ~90 atomics/us, MI355X_MICROARCH.md; frames of cheap
+                // pixels come close to that), which fits the gain growing as the pixels get cheaper: 4K grids
+                // of 1.8 k ... 10 M triangles +32 ... +4 %, Cornell / Default at 4K +0.5 %; at 1080p the cache-resident
+                // scenes lose to a longer tail (Cornell -2 %, Default -0.5 %) and keep one counter (profiles/r1/exp_xcd_bands.log)
+                const size_t workingSet = (size_t)sc->dev.nNodes * 64 + (size_t)sc->dev.nRefs * 48;
+                SA.xcdBands = (uint32_t)(t->xcdBands >= 0 ? t->xcdBands : ((workingSet > (4u << 20) || npixPart >= (1u << 22)) ? 1 : 0));
+                SA.sample = A.sample; SA.pixelRays = A.pixelRays; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npixPart; SA.band = band;
+                SA.alphaOne = direct ? 1u : 0u;
+                mipt_tracer::LevelEv le{ nullptr, nullptr, 0 };
+                const bool prof = t->profileLevels && level_events(le, S);
+                HIPCHK(t, hipEventRecord(ka, S));
+                if (npixPart) launch_wavestack(SA, std::min<int>((int)((npixPart + 255) / 256), persistentBlocks), S);
+                HIPCHK(t, hipEventRecord(kb, S));
+                if (prof) HIPCHK(t, hipEventRecord(le.b, S));
+                t->launches++;
+            } else {
+                HIPCHK(t, hipEventRecord(ka, S));
+                for (uint32_t p0 = 0; p0 < npix; p0 += tile) {
+                    const uint32_t np = std::min(tile, npix - p0);
+                    HIPCHK(t, hipMemsetAsync(t->counts, 0, 64 * sizeof(uint32_t), S));
+                    A.pix0 = p0; A.npix = np;
+                    for (uint32_t k = 0; k < D; k++) {
+                        A.level = k;
+                        A.qin = t->q[k & 1]; A.qout = t->q[(k + 1) & 1];
+                        A.inCount = t->counts + k; A.outCount = t->counts + k + 1;
+                        int blocks = k == 0 ? std::min<int>((int)((np + 255) / 256), persistentBlocks) : persistentBlocks;
+                        mipt_tracer::LevelEv le{ nullptr, nullptr, (int)k };
+                        const bool prof = t->profileLevels && level_events(le, S);
+                        launch_level(A, k == 0, blocks, S);
+                        if (prof) HIPCHK(t, hipEventRecord(le.b, S));
+                        t->launches++;
+                    }
+                }
+                HIPCHK(t, hipEventRecord(kb, S));
+            }
+            if (!direct) {
+                // fold into the caller's buffers, in frame order
+                hipStream_t F = pipe ? t->fold : S;
+                if (pipe) { HIPCHK(t, hipEventRecord(t->kernEv[slot], S)); HIPCHK(t, hipStreamWaitEvent(F, t->kernEv[slot], 0)); }
+                const float weight = (float)(1.0 / (frame + 1.0));       // CUDATracerProg.cu:878
+                mipt_tracer::LevelEv ae{ nullptr, nullptr, -1 };
+                const bool prof = t->profileLevels && level_events(ae, F);
+                launch_accumulate(sample, acc_dev, ldr_dev, weight, sum_mode, zeroAfter ? 1 : 0, band, 0, npixPart, F);
+                if (prof) HIPCHK(t, hipEventRecord(ae.b, F));
+                if (pipe) { HIPCHK(t, hipEventRecord(t->foldEv[slot], F)); t->foldValid[slot] = true; }
+            }
+            t->frames++;
+        }
+        HIPCHK(t, hipGetLastError());
+        if (t->pending.size() > 256 || t->levelPending.size() > 4096) resolve_events(t);
+        return MIPT_OK;
+    });
 }
 
 int mipt_trace(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, float* acc_dev, unsigned char* ldr_dev) {
@@ -826,63 +908,77 @@ int mipt_trace(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, float* a
 }
 
 int mipt_tonemap(mipt_tracer* t, const float* acc_dev, float scale, uint32_t n_pixels, unsigned char* ldr_dev) {
-    if (!t || !acc_dev || !ldr_dev) return fail(t, MIPT_E_INVALID, "null argument");
-    if (use(t)) return MIPT_E_HIP;
-    launch_tonemap(acc_dev, scale, n_pixels, ldr_dev, t->stream);
-    HIPCHK(t, hipGetLastError());
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t || !acc_dev || !ldr_dev) return fail(t, MIPT_E_INVALID, "null argument");
+        if (use(t)) return MIPT_E_HIP;
+        launch_tonemap(acc_dev, scale, n_pixels, ldr_dev, t->stream);
+        HIPCHK(t, hipGetLastError());
+        return MIPT_OK;
+    });
 }
 
 int mipt_last_sample(mipt_tracer* t, float* rgb_host, uint32_t* rays_host, uint32_t n_pixels) {
-    if (!t) return MIPT_E_INVALID;
-    if (use(t)) return MIPT_E_HIP;
-    if (n_pixels > (t->lastSlot ? t->ringPixels : t->samplePixels)) return fail(t, MIPT_E_INVALID, "no sample of that size");
-    HIPCHK(t, hipStreamSynchronize(t->stream));
-    if (rgb_host) {
-        std::vector<float> tmp((size_t)n_pixels * 4);
-        HIPCHK(t, hipMemcpy(tmp.data(), t->lastSlot ? t->ring[t->lastSlot] : t->sample, tmp.size() * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n_pixels; i++) { rgb_host[i * 3] = tmp[i * 4]; rgb_host[i * 3 + 1] = tmp[i * 4 + 1]; rgb_host[i * 3 + 2] = tmp[i * 4 + 2]; }
-    }
-    if (rays_host) {
-        if (!t->pixelRays || t->pixelRaysCap < n_pixels) return fail(t, MIPT_E_INVALID, "count_pixel_rays was not enabled");
-        HIPCHK(t, hipMemcpy(rays_host, t->pixelRays, (size_t)n_pixels * 4, hipMemcpyDeviceToHost));
-    }
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t) return MIPT_E_INVALID;
+        if (use(t)) return MIPT_E_HIP;
+        if (t->sampleConsumed) return fail(t, MIPT_E_INVALID, "the last frame's sample buffer was consumed by its fold (or summed straight into the accumulation buffer): set option keep_sample = 1 before rendering");
+        if (n_pixels > (t->lastSlot ? t->ringPixels : t->samplePixels)) return fail(t, MIPT_E_INVALID, "no sample of that size");
+        HIPCHK(t, hipStreamSynchronize(t->stream));
+        if (rgb_host) {
+            std::vector<float> tmp((size_t)n_pixels * 4);
+            HIPCHK(t, hipMemcpy(tmp.data(), t->lastSlot ? t->ring[t->lastSlot] : t->sample, tmp.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n_pixels; i++) { rgb_host[i * 3] = tmp[i * 4]; rgb_host[i * 3 + 1] = tmp[i * 4 + 1]; rgb_host[i * 3 + 2] = tmp[i * 4 + 2]; }
+        }
+        if (rays_host) {
+            if (!t->pixelRays || t->pixelRaysCap < n_pixels) return fail(t, MIPT_E_INVALID, "count_pixel_rays was not enabled");
+            HIPCHK(t, hipMemcpy(rays_host, t->pixelRays, (size_t)n_pixels * 4, hipMemcpyDeviceToHost));
+        }
+        return MIPT_OK;
+    });
 }
 
 int mipt_trace_rays(mipt_tracer* t, mipt_scene* sc, const float* o, const float* d, uint32_t n, mipt_hit* hits) {
-    if (!t || !sc || (n && (!o || !d || !hits))) return fail(t, MIPT_E_INVALID, "null argument");
-    if (sc->t != t) return fail(t, MIPT_E_INVALID, "scene belongs to another tracer");
-    if (use(t)) return MIPT_E_HIP;
-    launch_trace_rays(sc->dev, o, d, n, hits, t->stream);
-    HIPCHK(t, hipGetLastError());
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t || !sc || (n && (!o || !d || !hits))) return fail(t, MIPT_E_INVALID, "null argument");
+        if (sc->t != t) return fail(t, MIPT_E_INVALID, "scene belongs to another tracer");
+        if (use(t)) return MIPT_E_HIP;
+        launch_trace_rays(sc->dev, o, d, n, hits, t->stream);
+        HIPCHK(t, hipGetLastError());
+        return MIPT_OK;
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Device buffer layer (CUDABuffer's lazy host/device mirror; first touch is zero-filled, CUDABuffer.cpp:114-118,140-145)
 // ---------------------------------------------------------------------------------------------------------------
 int mipt_buffer_create(mipt_tracer* t, size_t size, mipt_buffer** out) {
-    if (!t || !out) return MIPT_E_INVALID;
-    mipt_buffer* b = new mipt_buffer(); b->t = t; b->size = size; *out = b;
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t || !out) return MIPT_E_INVALID;
+        mipt_buffer* b = new mipt_buffer(); b->t = t; b->size = size; *out = b;
+        return MIPT_OK;
+    });
 }
 void mipt_buffer_destroy(mipt_buffer* b) {
     if (!b) return;
     hipSetDevice(b->t->device);
-    if (b->cpu) hipHostFree(b->cpu);
-    if (b->gpu) hipFree(b->gpu);
+    if (b->cpu && b->ownCpu) hipHostFree(b->cpu);
+    if (b->gpu && b->ownGpu) hipFree(b->gpu);
     delete b;
 }
+// to_cpu / to_gpu of the reference (CUDABuffer.cpp:111-161).  Only the branches that move or allocate anything order
+// themselves after the frames in flight (use() -> join_aux); a call that finds the head where it is wanted touches no
+// stream, so reading the settings block before every Trace (CUDATracerProg.cu:942) does not serialise the frame pipeline.
 static bool buf_to_cpu(mipt_buffer* b) {
-    if (use(b->t)) return false;
     size_t sz = b->size ? b->size : 1;
     switch (b->head) {
         case MIPT_HEAD_UNINITIALIZED:
+            if (use_device(b->t)) return false;
             if (hipHostMalloc(&b->cpu, sz, hipHostMallocDefault) != hipSuccess) return false;
+            b->ownCpu = true;
             memset(b->cpu, 0, sz); b->head = MIPT_HEAD_AT_CPU; break;
         case MIPT_HEAD_AT_GPU:
-            if (!b->cpu && hipHostMalloc(&b->cpu, sz, hipHostMallocDefault) != hipSuccess) return false;
+            if (use(b->t)) return false;
+            if (!b->cpu) { if (hipHostMalloc(&b->cpu, sz, hipHostMallocDefault) != hipSuccess) return false; b->ownCpu = true; }
             // blocking copy ordered after the tracer's stream, as the reference's default-stream cudaMemcpy is
             if (hipStreamSynchronize(b->t->stream) != hipSuccess) return false;
             if (hipMemcpy(b->cpu, b->gpu, b->size, hipMemcpyDeviceToHost) != hipSuccess) return false;
@@ -892,16 +988,18 @@ static bool buf_to_cpu(mipt_buffer* b) {
     return true;
 }
 static bool buf_to_gpu(mipt_buffer* b) {
-    if (use(b->t)) return false;
     size_t sz = b->size ? b->size : 1;
     switch (b->head) {
         case MIPT_HEAD_UNINITIALIZED:
+            if (use(b->t)) return false;
             if (hipMalloc(&b->gpu, sz) != hipSuccess) return false;
+            b->ownGpu = true;
             if (hipMemsetAsync(b->gpu, 0, sz, b->t->stream) != hipSuccess) return false;
             if (hipStreamSynchronize(b->t->stream) != hipSuccess) return false;
             b->head = MIPT_HEAD_AT_GPU; break;
         case MIPT_HEAD_AT_CPU:
-            if (!b->gpu && hipMalloc(&b->gpu, sz) != hipSuccess) return false;
+            if (use(b->t)) return false;
+            if (!b->gpu) { if (hipMalloc(&b->gpu, sz) != hipSuccess) return false; b->ownGpu = true; }
             if (hipStreamSynchronize(b->t->stream) != hipSuccess) return false;
             if (hipMemcpy(b->gpu, b->cpu, b->size, hipMemcpyHostToDevice) != hipSuccess) return false;
             b->head = MIPT_HEAD_SYNCED; break;
@@ -915,57 +1013,119 @@ void* mipt_buffer_mutable_cpu_data(mipt_buffer* b) { if (!b || !buf_to_cpu(b)) r
 void* mipt_buffer_mutable_gpu_data(mipt_buffer* b) { if (!b || !buf_to_gpu(b)) return nullptr; b->head = MIPT_HEAD_AT_GPU; return b->gpu; }
 int mipt_buffer_head(const mipt_buffer* b) { return b ? b->head : MIPT_E_INVALID; }
 size_t mipt_buffer_size(const mipt_buffer* b) { return b ? b->size : 0; }
-int mipt_buffer_async_gpu_push(mipt_buffer* b) {
+// CUDABuffer::set_cpu_data / set_gpu_data (CUDABuffer.cpp:166-191): the buffer adopts caller-owned memory of at least
+// size() bytes without taking ownership; the head moves to that side.
+int mipt_buffer_set_cpu_data(mipt_buffer* b, void* data) {
+    if (!b || !data) return MIPT_E_INVALID;
+    if (use_device(b->t)) return MIPT_E_HIP;
+    if (b->cpu && b->ownCpu) hipHostFree(b->cpu);
+    b->cpu = data; b->ownCpu = false; b->head = MIPT_HEAD_AT_CPU;
+    return MIPT_OK;
+}
+int mipt_buffer_set_gpu_data(mipt_buffer* b, void* data_dev) {
+    if (!b || !data_dev) return MIPT_E_INVALID;
+    if (use(b->t)) return MIPT_E_HIP;                 // frames in flight may still be using the memory let go of here
+    if (b->gpu && b->ownGpu) { hipStreamSynchronize(b->t->stream); hipFree(b->gpu); }
+    b->gpu = data_dev; b->ownGpu = false; b->head = MIPT_HEAD_AT_GPU;
+    return MIPT_OK;
+}
+// CUDABuffer::async_gpu_push(stream) (CUDABuffer.cpp:208-224): head must be at the CPU; the copy is queued on the
+// caller's stream (NULL: the tracer's) and the caller synchronises on it before using the device side.
+int mipt_buffer_async_gpu_push_on(mipt_buffer* b, void* hip_stream) {
     if (!b || b->head != MIPT_HEAD_AT_CPU) return MIPT_E_INVALID;
     mipt_tracer* t = b->t;
     if (use(t)) return MIPT_E_HIP;
-    if (!b->gpu) HIPCHK(t, hipMalloc(&b->gpu, b->size ? b->size : 1));
-    HIPCHK(t, hipMemcpyAsync(b->gpu, b->cpu, b->size, hipMemcpyHostToDevice, t->stream));
+    if (!b->gpu) { HIPCHK(t, hipMalloc(&b->gpu, b->size ? b->size : 1)); b->ownGpu = true; }
+    HIPCHK(t, hipMemcpyAsync(b->gpu, b->cpu, b->size, hipMemcpyHostToDevice, hip_stream ? (hipStream_t)hip_stream : t->stream));
     b->head = MIPT_HEAD_SYNCED;
     return MIPT_OK;
 }
+int mipt_buffer_async_gpu_push(mipt_buffer* b) { return mipt_buffer_async_gpu_push_on(b, nullptr); }
 
 int mipt_malloc(mipt_tracer* t, size_t size, void** dev_out) {
-    if (!t || !dev_out) return MIPT_E_INVALID;
-    if (use(t)) return MIPT_E_HIP;
-    HIPCHK(t, hipMalloc(dev_out, size ? size : 1));
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t || !dev_out) return MIPT_E_INVALID;
+        if (use(t)) return MIPT_E_HIP;
+        HIPCHK(t, hipMalloc(dev_out, size ? size : 1));
+        return MIPT_OK;
+    });
 }
 int mipt_free(mipt_tracer* t, void* dev) { if (!t) return MIPT_E_INVALID; if (use(t)) return MIPT_E_HIP; if (dev) HIPCHK(t, hipFree(dev)); return MIPT_OK; }
 int mipt_upload(mipt_tracer* t, void* dev, const void* host, size_t size) {
-    if (!t || (size && (!dev || !host))) return MIPT_E_INVALID;
-    if (use(t)) return MIPT_E_HIP;
-    HIPCHK(t, hipStreamSynchronize(t->stream));
-    if (size) HIPCHK(t, hipMemcpy(dev, host, size, hipMemcpyHostToDevice));
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t || (size && (!dev || !host))) return MIPT_E_INVALID;
+        if (use(t)) return MIPT_E_HIP;
+        HIPCHK(t, hipStreamSynchronize(t->stream));
+        if (size) HIPCHK(t, hipMemcpy(dev, host, size, hipMemcpyHostToDevice));
+        return MIPT_OK;
+    });
 }
 int mipt_download(mipt_tracer* t, void* host, const void* dev, size_t size) {
-    if (!t || (size && (!dev || !host))) return MIPT_E_INVALID;
-    if (use(t)) return MIPT_E_HIP;
-    HIPCHK(t, hipStreamSynchronize(t->stream));
-    if (size) HIPCHK(t, hipMemcpy(host, dev, size, hipMemcpyDeviceToHost));
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t || (size && (!dev || !host))) return MIPT_E_INVALID;
+        if (use(t)) return MIPT_E_HIP;
+        HIPCHK(t, hipStreamSynchronize(t->stream));
+        if (size) HIPCHK(t, hipMemcpy(host, dev, size, hipMemcpyDeviceToHost));
+        return MIPT_OK;
+    });
 }
 int mipt_memset(mipt_tracer* t, void* dev, int value, size_t size) {
-    if (!t || (size && !dev)) return MIPT_E_INVALID;
-    if (use(t)) return MIPT_E_HIP;
-    if (size) HIPCHK(t, hipMemsetAsync(dev, value, size, t->stream));
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t || (size && !dev)) return MIPT_E_INVALID;
+        if (use(t)) return MIPT_E_HIP;
+        if (size) HIPCHK(t, hipMemsetAsync(dev, value, size, t->stream));
+        return MIPT_OK;
+    });
 }
 
 int mipt_test_math(mipt_tracer* t, int fn, const float* a, const float* b, uint32_t n, float* out) {
-    if (!t || !a || !out) return MIPT_E_INVALID;
-    if (use(t)) return MIPT_E_HIP;
-    float *da = nullptr, *db = nullptr, *dout = nullptr;
-    size_t bytes = (size_t)std::max<uint32_t>(n, 1) * 4;
-    HIPCHK(t, hipMalloc((void**)&da, bytes)); HIPCHK(t, hipMalloc((void**)&db, bytes)); HIPCHK(t, hipMalloc((void**)&dout, bytes));
-    HIPCHK(t, hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
-    if (b) HIPCHK(t, hipMemcpy(db, b, (size_t)n * 4, hipMemcpyHostToDevice)); else HIPCHK(t, hipMemset(db, 0, bytes));
-    launch_test_math(fn, da, db, n, dout, t->stream);
-    HIPCHK(t, hipStreamSynchronize(t->stream));
-    HIPCHK(t, hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
-    hipFree(da); hipFree(db); hipFree(dout);
-    return MIPT_OK;
+    return guarded(t, [&]() -> int {
+        if (!t || !a || !out) return MIPT_E_INVALID;
+        if (use(t)) return MIPT_E_HIP;
+        float *da = nullptr, *db = nullptr, *dout = nullptr;
+        size_t bytes = (size_t)std::max<uint32_t>(n, 1) * 4;
+        HIPCHK(t, hipMalloc((void**)&da, bytes)); HIPCHK(t, hipMalloc((void**)&db, bytes)); HIPCHK(t, hipMalloc((void**)&dout, bytes));
+        HIPCHK(t, hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
+        if (b) HIPCHK(t, hipMemcpy(db, b, (size_t)n * 4, hipMemcpyHostToDevice)); else HIPCHK(t, hipMemset(db, 0, bytes));
+        launch_test_math(fn, da, db, n, dout, t->stream);
+        HIPCHK(t, hipStreamSynchronize(t->stream));
+        HIPCHK(t, hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+        hipFree(da); hipFree(db); hipFree(dout);
+        return MIPT_OK;
+    });
+}
+
+// VALU issue calibration (csrc/microbench.hip): `iters` x 64 independent v_fma_f32 per wave on numCU x blocks_per_cu
+// blocks of 256 threads; median per-wave shader-clock cycles and 100 MHz ticks of the loop, HIP-event time of the launch.
+int mipt_test_issue(mipt_tracer* t, uint32_t blocks_per_cu, uint32_t iters, mipt_issue_result* out) {
+    return guarded(t, [&]() -> int {
+        if (!t || !out || blocks_per_cu < 1 || blocks_per_cu > 8 || iters < 1 || iters > (1u << 24)) return fail(t, MIPT_E_INVALID, "test_issue: blocks_per_cu 1..8, iters 1..2^24");
+        if (use(t)) return MIPT_E_HIP;
+        const int blocks = t->numCU * (int)blocks_per_cu;
+        const size_t waves = (size_t)blocks * 4;
+        unsigned long long* stamps = nullptr; float* sink = nullptr;
+        HIPCHK(t, hipMalloc((void**)&stamps, waves * 2 * sizeof(unsigned long long)));
+        HIPCHK(t, hipMalloc((void**)&sink, 256 * sizeof(float)));
+        hipEvent_t a, b;
+        HIPCHK(t, hipEventCreate(&a)); HIPCHK(t, hipEventCreate(&b));
+        launch_test_issue(iters, blocks, stamps, sink, t->stream);            // warm-up: code object load, clocks
+        HIPCHK(t, hipEventRecord(a, t->stream));
+        launch_test_issue(iters, blocks, stamps, sink, t->stream);
+        HIPCHK(t, hipEventRecord(b, t->stream));
+        HIPCHK(t, hipStreamSynchronize(t->stream));
+        float ms = 0.f; HIPCHK(t, hipEventElapsedTime(&ms, a, b));
+        std::vector<unsigned long long> h(waves * 2);
+        HIPCHK(t, hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> cyc(waves), rt(waves);
+        for (size_t w = 0; w < waves; w++) { cyc[w] = h[2 * w]; rt[w] = h[2 * w + 1]; }
+        std::sort(cyc.begin(), cyc.end()); std::sort(rt.begin(), rt.end());
+        out->ms = ms; out->waves = (uint32_t)waves; out->simds = (uint32_t)t->numCU * 4u;
+        out->wave_instructions = (uint64_t)waves * iters * 64ull;
+        out->median_cycles = (double)cyc[waves / 2]; out->max_cycles = (double)cyc[waves - 1];
+        out->median_realtime_ticks = (double)rt[waves / 2];
+        hipEventDestroy(a); hipEventDestroy(b); hipFree(stamps); hipFree(sink);
+        return MIPT_OK;
+    });
 }
 
 }  // extern "C"

@@ -5,8 +5,14 @@
 //  * SBVH algorithm and constants: CUDATracer/SplitBVHBuilder.cpp:57-512, SplitBVHBuilder.hpp:57-81
 //    (splitAlpha 1e-5, MaxDepth 64, MaxSpatialDepth 48, 32 spatial bins).  That file is dead code in the reference
 //    (not compiled, refers to an undeclared Platform) and depends on an inverted AABB::grow
-//    (Types.hpp:190); this is a fresh implementation of the published algorithm with a correct grow() and the SAH
-//    constants pinned in BvhParams.
+//    (Types.hpp:190).  Provenance, stated plainly: the SBVH core below -- build(), find_object_split,
+//    do_object_split, find_spatial_split, split_ref, do_spatial_split -- RESTATES the reference's (NVIDIA-derived)
+//    SplitBVHBuilder.cpp:132-512 step for step (same reference-stack tail, same right-bounds sweep, same tie-break
+//    on equal centroids, same empty-side fallback, same unsplit / duplicate SAH triple), because BASELINE.json's
+//    north_star asks for SplitBVHBuilder's tree; it is a transliteration onto this file's types with a correct
+//    grow() and the SAH constants pinned in BvhParams, not an independent derivation from the paper.  Everything
+//    else in this file (parallel splice, depth-capped median fallback, 4-wide collapse + quantisation + its
+//    verification, validate_bvh, refit_bvh, the flat output layout) has no counterpart in the reference.
 //  * median split: CUDATracer/Types.hpp:312-413 (longest centroid axis, nth_element at n/2, leaf <= 4, depth <= 32),
 //    applied here to the whole scene's triangle list instead of once per mesh.
 // Differences from the spec, all build-side: one tree over all meshes (no per-mesh loop); leaves hold at most 15
@@ -50,6 +56,18 @@ struct Box {
 };
 struct Ref { int32_t tri; Box b; };
 struct Spec { int n = 0; Box b; };
+
+}  // namespace
+// compiled-in constants that shape the tree but are not in BvhParams: part of the BVH cache key (api.hip)
+uint64_t bvh_build_constants_hash() {
+    BvhParams d;
+    uint32_t nc, ml = d.minLeafSize; memcpy(&nc, &d.nodeCost, 4);
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (uint64_t w : { (uint64_t)kSpatialBins, (uint64_t)kMaxSpatialDepth, (uint64_t)kMaxBvhDepth, (uint64_t)kMaxWideStack,
+                        (uint64_t)kLdsSceneFloat4, (uint64_t)nc, (uint64_t)ml }) { h ^= w; h *= 0x100000001b3ull; h ^= h >> 31; }
+    return h;
+}
+namespace {
 
 int ceil_log2(uint32_t n) { int l = 0; while ((1u << l) < n && l < 31) l++; return l; }
 

@@ -52,6 +52,8 @@ constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kEmptyRef = 0x80000000u; // 4-wide nodes: "no child" (a leaf of zero references)
 inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return kLeafFlag | (count << 27) | first; }
 
+uint64_t bvh_build_constants_hash();     // the builder's compiled-in constants (bins, depth caps, LDS window, node cost ...)
+
 // returns empty string on success, otherwise an error message
 std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOut& out);
 

@@ -74,6 +74,7 @@ struct StackArgs {
     float* sample; uint32_t* pixelRays; unsigned long long* stats;
     uint32_t pix0, npix;         // npix: pixels of this handle's partition (the whole frame without one)
     Band band;
+    uint32_t alphaOne;           // 1: `sample` is the caller's accumulation buffer (sum mode): every primary ray also writes alpha = 1
 };
 
 struct DfsArgs {
@@ -86,10 +87,11 @@ void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s);
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s);
 bool wavestack_scene_in_lds(const SceneDev& S);    // true: k_wavestack walks this scene from LDS (BVH2, fits the window and the LDS stack)
 void launch_dfs(const DfsArgs& a, int blocks, hipStream_t s);
-void launch_accumulate(const float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, Band band,
+void launch_accumulate(float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, int zeroAfter, Band band,
                        uint32_t pix0, uint32_t npix, hipStream_t s);
 void launch_tonemap(const float* acc, float scale, uint32_t npix, unsigned char* ldr, hipStream_t s);
 void launch_trace_rays(const SceneDev& S, const float* o, const float* d, uint32_t n, void* hits, hipStream_t s);
+void launch_test_issue(uint32_t iters, int blocks, unsigned long long* stamps, float* sink, hipStream_t s);   // microbench.hip
 void launch_test_math(int fn, const float* a, const float* b, uint32_t n, float* out, hipStream_t s);
 
 }  // namespace mipt

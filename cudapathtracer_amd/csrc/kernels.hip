@@ -782,6 +782,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                         pix = A.pix0 + pbase + rank; node = 1; beta = mk3(1.f, 1.f, 1.f);
                         if (A.band.pixels) pix = band_pixel(A.band, pix);
                         gen_primary(A.F, pix, o, d, s0);
+                        if (A.alphaOne) A.sample[(size_t)pix * 4 + 3] = 1.f;
                     } else {
                         const uint32_t e = sp + (rank - got);
                         float4 ra = qa[e], rb = qb[e], rc = qc[e];
@@ -1049,23 +1050,26 @@ MIPT_DEV unsigned char tonemap1(float x) {
     x = det_pow_gamma(x);
     return (unsigned char)(int)(x * 255);
 }
-__global__ void __launch_bounds__(kBlock) k_accumulate(const float4* sample, float4* acc, uchar4* ldr, float weight, int sumMode,
+// zeroAfter: the sample slot is cleared as soon as it has been read, so the next frame that uses it needs no clear of
+// its own (one 16 B/pixel fill kernel per frame less)
+__global__ void __launch_bounds__(kBlock) k_accumulate(float4* sample, float4* acc, uchar4* ldr, float weight, int sumMode, int zeroAfter,
                                                         Band band, uint32_t pix0, uint32_t npix) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= npix) return;
     uint32_t p = pix0 + i;
     if (band.pixels) p = band_pixel(band, p);
     float4 c = sample[p], a = acc[p];
+    if (zeroAfter) sample[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     float r, g, b;
     if (sumMode) { r = a.x + c.x; g = a.y + c.y; b = a.z + c.z; }
     else { r = a.x * (1 - weight) + c.x * weight; g = a.y * (1 - weight) + c.y * weight; b = a.z * (1 - weight) + c.z * weight; }
     acc[p] = make_float4(r, g, b, 1.f);
     if (ldr) ldr[p] = make_uchar4(tonemap1(r), tonemap1(g), tonemap1(b), 255);
 }
-void launch_accumulate(const float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, Band band, uint32_t pix0, uint32_t npix, hipStream_t s) {
+void launch_accumulate(float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, int zeroAfter, Band band, uint32_t pix0, uint32_t npix, hipStream_t s) {
     if (!npix) return;
-    hipLaunchKernelGGL(k_accumulate, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const float4*)sample, (float4*)acc, (uchar4*)ldr,
-                       weight, sumMode, band, pix0, npix);
+    hipLaunchKernelGGL(k_accumulate, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (float4*)sample, (float4*)acc, (uchar4*)ldr,
+                       weight, sumMode, zeroAfter, band, pix0, npix);
 }
 __global__ void __launch_bounds__(kBlock) k_tonemap(const float4* acc, float scale, uint32_t npix, uchar4* ldr) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;

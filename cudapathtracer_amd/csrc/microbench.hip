@@ -1,0 +1,47 @@
+// microbench.hip -- calibration kernels for the roofline bench.py reports (no counterpart in the reference).
+//
+// k_test_issue settles what one SIMD of gfx950 can issue: `iters` x 64 independent v_fma_f32 per wave (8 accumulator
+// chains, so no instruction waits for the one before it), launched on the integrator's own grid shape
+// (256-thread blocks, numCU x blocksPerCU blocks: one wave per SIMD per block, blocksPerCU waves per SIMD).
+// Each wave stamps the shader clock (s_memtime) and the 100 MHz wall clock (s_memrealtime) around its loop and lane 0
+// stores them with plain vector stores, so the host gets wave-instructions per SIMD-cycle from the kernel's own clock
+// (no assumption about the clock the chip holds under load) next to the HIP-event time of the launch.
+// MI355X_MICROARCH.md states 2 cycles per wave64 VALU instruction with several waves per SIMD and 4 for a wave alone;
+// scripts/issue_calibration.py records what this kernel measures, with the SQ counters of the same launches.
+#include "kernels.h"
+
+namespace mipt {
+
+#define MIPT_FMA8_TXT                     \
+    "v_fma_f32 %0, %8, %9, %0\n\t"        \
+    "v_fma_f32 %1, %8, %9, %1\n\t"        \
+    "v_fma_f32 %2, %8, %9, %2\n\t"        \
+    "v_fma_f32 %3, %8, %9, %3\n\t"        \
+    "v_fma_f32 %4, %8, %9, %4\n\t"        \
+    "v_fma_f32 %5, %8, %9, %5\n\t"        \
+    "v_fma_f32 %6, %8, %9, %6\n\t"        \
+    "v_fma_f32 %7, %8, %9, %7\n\t"
+// one asm statement for all 64: between separate asm statements the compiler pads with s_nop
+#define MIPT_FMA64(x_, y_)                                                                                            \
+    asm volatile(MIPT_FMA8_TXT MIPT_FMA8_TXT MIPT_FMA8_TXT MIPT_FMA8_TXT MIPT_FMA8_TXT MIPT_FMA8_TXT MIPT_FMA8_TXT MIPT_FMA8_TXT \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x_), "v"(y_))
+
+__global__ void __launch_bounds__(256) k_test_issue(uint32_t iters, float seed, unsigned long long* stamps, float* sink) {
+    float a0 = seed + (float)threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float x = 0.999f + seed, y = 1e-3f * seed;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t i = 0; i < iters; i++) {
+        MIPT_FMA64(x, y);
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63u) == 0u) { stamps[2 * (size_t)wave] = c1 - c0; stamps[2 * (size_t)wave + 1] = r1 - r0; }
+    const float s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    if (s == 12345.678f) sink[threadIdx.x] = s;      // keeps the chains live; practically never taken
+}
+
+void launch_test_issue(uint32_t iters, int blocks, unsigned long long* stamps, float* sink, hipStream_t s) {
+    hipLaunchKernelGGL(k_test_issue, dim3(blocks), dim3(256), 0, s, iters, 1.0f, stamps, sink);
+}
+
+}  // namespace mipt

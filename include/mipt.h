@@ -114,7 +114,7 @@ void mipt_scene_destroy(mipt_scene*);
  * CUDAScene, i.e. a full BVH build.  `desc` holds the same meshes with the same index buffers (the triangle count of
  * the scene must match); positions, normals and materials are taken from it, the tree keeps its shape and its boxes
  * are re-fitted bottom-up (4-wide nodes re-quantised), and the device buffers are overwritten in place after the
- * tracer's pending frames have finished.  Env map, sky and BVH parameters of the desc are ignored.  Results are those
+ * tracer's pending frames have finished.  The sky light is taken from the desc as well; its env map and BVH parameters are ignored.  Results are those
  * of a scene created from `desc` (closest hits do not depend on the tree); traversal cost grows as the geometry drifts
  * from the one the tree was built for, and spatial-split leaves lose their clipping. */
 int  mipt_scene_refit(mipt_scene*, const mipt_scene_desc* desc);
@@ -178,7 +178,9 @@ int  mipt_render(mipt_tracer*, mipt_scene*, const mipt_settings*, uint32_t first
                  uint32_t frame_stride, int sum_mode, float* acc_dev, unsigned char* ldr_dev);
 /* accumulate-free tonemap of an accumulation buffer (scale applied first): CUDATracerProg.cu:908-919 */
 int  mipt_tonemap(mipt_tracer*, const float* acc_dev, float scale, uint32_t n_pixels, unsigned char* ldr_dev);
-/* radiance of the last frame traced, before accumulation (w*h*3 floats) and its per-pixel ray counts; for parity tests */
+/* radiance of the last frame traced, before accumulation (w*h*3 floats) and its per-pixel ray counts; for parity tests.
+ * A pipelined frame's fold clears its sample buffer (and a sum-mode frame without an LDR target has none): set option
+ * "keep_sample" = 1 (or "count_pixel_rays" = 1, or "pipeline_frames" = 0) before rendering, else MIPT_E_INVALID. */
 int  mipt_last_sample(mipt_tracer*, float* rgb_host, uint32_t* rays_host, uint32_t n_pixels);
 
 /* closest hit for a fixed ray batch (the traversal kernel alone): TraceRay, CUDATracerProg.cu:543-794 */
@@ -196,6 +198,15 @@ void* mipt_buffer_mutable_gpu_data(mipt_buffer*);
 int   mipt_buffer_head(const mipt_buffer*);
 size_t mipt_buffer_size(const mipt_buffer*);
 int   mipt_buffer_async_gpu_push(mipt_buffer*);           /* CUDABuffer::async_gpu_push on the tracer's stream */
+/* CUDABuffer::async_gpu_push(const cudaStream_t&) (CUDABuffer.hpp:27, CUDABuffer.cpp:208-224): head must be at the CPU;
+ * the host-to-device copy is queued on the caller's HIP stream (NULL = the tracer's) and the head becomes SYNCED; the
+ * caller synchronises on that stream before the device side is used. */
+int   mipt_buffer_async_gpu_push_on(mipt_buffer*, void* hip_stream);
+/* CUDABuffer::set_cpu_data / set_gpu_data (CUDABuffer.hpp:18,20; CUDABuffer.cpp:166-191): the buffer adopts caller-owned
+ * memory of at least size() bytes (pinned or pageable host memory / device memory on the tracer's GPU) without taking
+ * ownership; what the buffer had allocated on that side is freed; the head moves to that side. */
+int   mipt_buffer_set_cpu_data(mipt_buffer*, void* data);
+int   mipt_buffer_set_gpu_data(mipt_buffer*, void* data_dev);
 /* raw helpers for callers that manage device memory themselves */
 int   mipt_malloc(mipt_tracer*, size_t size, void** dev_out);
 int   mipt_free(mipt_tracer*, void* dev);
@@ -227,6 +238,17 @@ size_t   mipt_rgbe_encode(const float* rgb, uint32_t width, uint32_t height, uns
 /* ---- device math self-test (used by the parity tests of the portable transcendentals) --------------------- */
 /* fn 0 sin 1 cos 2 atan2(a,b) 3 acos 4 x^(1/2.2) 5 x^5 6 x^10 ; host arrays */
 int  mipt_test_math(mipt_tracer*, int fn, const float* a, const float* b, uint32_t n, float* out);
+
+/* ---- VALU issue calibration (no counterpart in the reference; evidence for bench.py's VALU roofline) --------------
+ * Launches, on the integrator's grid shape (256-thread blocks, CUs x blocks_per_cu blocks = blocks_per_cu waves per
+ * SIMD), a kernel in which every wave issues iters x 64 independent v_fma_f32, and reports the HIP-event time of the
+ * launch and the median over waves of the loop's duration in shader-clock cycles (s_memtime) and 100 MHz ticks
+ * (s_memrealtime).  wave-instructions per SIMD-cycle = blocks_per_cu * iters * 64 / median_cycles. */
+typedef struct {
+    double ms; uint64_t wave_instructions; uint32_t waves, simds;
+    double median_cycles, max_cycles, median_realtime_ticks;
+} mipt_issue_result;
+int  mipt_test_issue(mipt_tracer*, uint32_t blocks_per_cu, uint32_t iters, mipt_issue_result* out);
 
 #ifdef __cplusplus
 }

@@ -38,12 +38,112 @@ int main() { TypedBuffer<PathTraceSettings> s; (void)sizeof(s); PathTracer* p = 
 """
 
 
+# a caller that touches every member the reference declares on CUDAScene (CUDATracer.hpp:205-226) and the three
+# CUDABuffer members no reference app calls (CUDABuffer.hpp:18,20,27); it doubles as the GPU end-to-end test below
+ACCESSOR_CALLER = r"""
+#include <cstdio>
+#include <vector>
+#include "RendererWindow.hpp"
+using namespace CUDATracer;
+typedef struct ihipStream_t* hipStream_t;          // what <hip/hip_runtime.h> declares; this caller needs no HIP headers
+int main() {
+    SurfaceMaterial mat{}; mat.color = 0.8f; mat.roughness = 0.5f; mat.opacity = 1.0f; mat.n = 2.5f;
+    Scene scn{ {{0.98f, 0.97f, 0.99f}, -Math::normalize(Math::vec3f{1, 1, 1}), 5.f}, {} };
+    scn.objects.push_back(ConstructMesh(MakeQuad(), mat, Math::MatMul(Math::MakeTranslate(Math::vec3f{-4, 0, -4}), Math::MakeScale(Math::vec3f{8, 1, 8}))));
+    scn.objects.push_back(ConstructMesh(MakeCube(), mat, Math::MakeTranslate(Math::vec3f{0.5f, 0.f, -0.5f})));
+    CUDAScene cs(scn);
+    const SceneInfoHeader& info = cs.GetInfo();
+    const MeshInfoHeader& cube = cs.GetMesh(1);
+    std::printf("meshes %u verts %u idx %u total %u sky %.2f\n", info.meshCnt, cube.vertexCnt, cube.indicesCnt, cube.TotalSize(), info.skyLight.intensity);
+    if (info[1] != &cube || cube.GetVertices()[0].position.x != scn.objects[1].GetVertices()[0].position.x || cube.GetIndices()[2] != scn.objects[1].GetIndices()[2]) return 2;
+
+    const unsigned w = 96, h = 64;
+    TypedBuffer<PathTraceSettings> settings;
+    auto& st = settings.GetMutable<0>();
+    st.viewportWidth = w; st.viewportHeight = h; st.maxDepth = 3; st.frameID = 0;
+    Scenes::CameraParams cp; cp.pos = { -3, 1.5f, 0 }; cp.azimuth = 0; cp.zenith = 1.9f; cp.fov = 1.0f;
+    Scenes::UpdateCam(cp, st.cam);
+    CUDABuffer acc(w * h * 16), ldr(w * h * 4);
+    PathTracer* tracer = MakeCUDATracerProg();
+    auto mean = [&](int channel) {
+        const float* a = (const float*)acc.cpu_data(); double m = 0;
+        for (unsigned i = 0; i < w * h; i++) m += a[i * 4 + channel];
+        return m / (w * h);
+    };
+    tracer->Trace(cs, settings, (float*)acc.mutable_gpu_data(), (char*)ldr.mutable_gpu_data());
+    const double r0 = mean(0), b0 = mean(2);
+
+    // edit the cube's material and lift it through the mutable accessors; the next Trace sees both
+    MeshInfoHeader& mc = cs.GetMeshMutable(1);
+    mc.material.color = Math::vec3f{ 0.9f, 0.05f, 0.05f };
+    for (unsigned i = 0; i < mc.vertexCnt; i++) mc.GetVertices()[i].position.y += 0.25f;
+    cs.GetInfoMutable().skyLight.intensity = 5.f;
+    if (!cs.Dirty()) return 3;
+    tracer->Trace(cs, settings, (float*)acc.mutable_gpu_data(), (char*)ldr.mutable_gpu_data());
+    if (cs.Dirty()) return 4;
+    const double r1 = mean(0), b1 = mean(2);
+    std::printf("before r %.4f b %.4f  after r %.4f b %.4f\n", r0, b0, r1, b1);
+
+    // the same edit made on the host scene and uploaded as a new CUDAScene must give the same frame
+    Scene scn2 = scn;
+    {
+        std::vector<Vertex> v = scn.objects[1].GetVertices();
+        for (auto& x : v) x.position.y += 0.25f;
+        SurfaceMaterial red = mat; red.color = Math::vec3f{ 0.9f, 0.05f, 0.05f };
+        scn2.objects[1] = Mesh(v, scn.objects[1].GetIndices(), red);
+    }
+    CUDAScene cs2(scn2);
+    CUDABuffer acc2(w * h * 16);
+    tracer->Trace(cs2, settings, (float*)acc2.mutable_gpu_data(), (char*)ldr.mutable_gpu_data());
+    const float* a = (const float*)acc.cpu_data(); const float* b = (const float*)acc2.cpu_data();
+    double worst = 0;
+    for (unsigned i = 0; i < w * h * 4; i++) { double e = std::fabs((double)a[i] - b[i]) / std::fmax(std::fabs((double)b[i]), 1e-3); if (e > worst) worst = e; }
+    std::printf("refit vs fresh scene: worst relative difference %.3g\n", worst);
+
+    // set_cpu_data / async_gpu_push(stream) / set_gpu_data
+    std::vector<float> mine(1024, 1.5f);
+    CUDABuffer buf(mine.size() * sizeof(float));
+    buf.set_cpu_data(mine.data());
+    if (buf.head() != CUDABuffer::HEAD_AT_CPU || buf.cpu_data() != mine.data()) return 5;
+    hipStream_t stream = nullptr;                        // the tracer's own stream
+    buf.async_gpu_push(stream);
+    if (buf.head() != CUDABuffer::SYNCED) return 6;
+    CUDABuffer view(mine.size() * sizeof(float));
+    view.set_gpu_data(const_cast<void*>(buf.gpu_data()));     // non-owning: `buf` keeps the allocation
+    if (view.head() != CUDABuffer::HEAD_AT_GPU) return 7;
+    const float* back = (const float*)view.cpu_data();        // blocking D2H after the push on the same stream
+    for (size_t i = 0; i < mine.size(); i++) if (back[i] != 1.5f) return 8;
+    std::printf("buffers ok\n");
+    delete tracer;
+    return ((r1 - b1) - (r0 - b0) > 0.005 && worst < 1e-4) ? 0 : 9;     // the frame turned redder; refit == fresh upload
+}
+"""
+
+
 def test_reference_style_caller_compiles(tmp_path):
-    src = tmp_path / "caller.cpp"
-    src.write_text(CALLER)
-    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "cudapathtracer_amd", "cpp"), str(src)],
-                       capture_output=True, text=True)
+    for name, text in (("caller.cpp", CALLER), ("accessors.cpp", ACCESSOR_CALLER)):
+        src = tmp_path / name
+        src.write_text(text)
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "cudapathtracer_amd", "cpp"), str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_scene_accessors_and_buffer_setters_end_to_end(tmp_path):
+    """CUDAScene::GetMesh / GetMeshMutable / GetInfo / GetInfoMutable and CUDABuffer::set_cpu_data / set_gpu_data /
+    async_gpu_push(stream) used the way a reference-style caller would: an edit through the mutable accessors reaches
+    the GPU with the next Trace and equals a freshly uploaded scene."""
+    libdir = os.path.join(ROOT, "cudapathtracer_amd")
+    src = tmp_path / "accessors.cpp"
+    src.write_text(ACCESSOR_CALLER)
+    exe = str(tmp_path / "accessors")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(libdir, "cpp"), str(src), "-o", exe, "-L", libdir, "-lmipt",
+                        "-Wl,-rpath," + libdir], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "meshes 2 verts 24 idx 36" in r.stdout and "buffers ok" in r.stdout
 
 
 def test_apps_are_built_and_link_only_libmipt():

@@ -150,8 +150,10 @@ def test_env_map_lookup(tracer, ptlib, oracle):
         cam = ptlib.make_camera((0, 0, 0), 2.0, zen, 1.0)
         s = ptlib.make_settings(cam, 96, 64, 3)
         acc, _ = dev_buffers(tracer, 96, 64, ldr=False)
+        tracer.set_option("keep_sample", 1)          # a pipelined frame's fold would clear the sample buffer
         tracer.render(sc, s, 0, 1, acc)
         rgb = tracer.last_sample(96 * 64)
+        tracer.set_option("keep_sample", 0)
         tracer.free(acc)
         r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, 1)
         assert np.array_equal(rgb.reshape(64, 96, 3), r["sample"])     # one contribution per pixel: exact
@@ -184,6 +186,7 @@ def test_tile_size_does_not_change_the_image(tracer, ptlib):
     acc, _ = dev_buffers(tracer, 200, 120, ldr=False)
     out = []
     try:
+        tracer.set_option("keep_sample", 1)
         tracer.set_option("integrator", 1)          # tiles exist only in the level-synchronous integrator
         for tile in (0, 4096, 777, 64):
             tracer.set_option("tile_pixels", tile)
@@ -195,6 +198,7 @@ def test_tile_size_does_not_change_the_image(tracer, ptlib):
         tracer.render(sc, s, 3, 1, acc)
         out.append((tracer.last_sample(200 * 120), tracer.counters().rays))
     finally:
+        tracer.set_option("keep_sample", 0)
         tracer.set_option("integrator", 0)
         tracer.set_option("tile_pixels", 0)
         tracer.free(acc)
@@ -283,6 +287,10 @@ def test_error_behaviour(tracer, ptlib):
     tracer.reset_counters()
     tracer.render(sc, ptlib.make_settings(cam, 16, 16, 0), 0, 1, acc)
     assert tracer.counters().rays == 0 and not tracer.last_sample(256).any()
+    # a pipelined frame's fold consumes its sample buffer: reading it back afterwards is an error, not stale data
+    tracer.render(sc, ptlib.make_settings(cam, 16, 16, 2), 0, 1, acc)
+    with pytest.raises(ptlib.MiptError, match="keep_sample"):
+        tracer.last_sample(256)
     tracer.free(acc)
 
 
