@@ -104,6 +104,7 @@ lib.mipt_scene_bvh_width.argtypes = [_vp]
 lib.mipt_scene_bvh_width.restype = C.c_uint32
 lib.mipt_trace.argtypes = [_vp, _vp, C.POINTER(Settings), _vp, _vp]
 lib.mipt_render.argtypes = [_vp, _vp, C.POINTER(Settings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _vp, _vp]
+lib.mipt_trace_static.argtypes = [_vp, _vp, C.POINTER(Settings), _vp, _vp]
 lib.mipt_buffer_async_gpu_push_on.argtypes = [_vp, _vp]
 lib.mipt_buffer_set_cpu_data.argtypes = [_vp, _vp]
 lib.mipt_buffer_set_gpu_data.argtypes = [_vp, _vp]
@@ -398,6 +399,10 @@ class Tracer:
 
     def trace(self, scene, settings, acc_dev, ldr_dev):
         self._chk(lib.mipt_trace(self.h, scene.h, C.byref(settings), acc_dev, ldr_dev), "trace")
+
+    def trace_static(self, scene, settings, acc_dev, ldr_dev):
+        """mipt_trace_static: the allocation-free variant of trace (<= 65536 pixels, maxDepth <= 8)."""
+        self._chk(lib.mipt_trace_static(self.h, scene.h, C.byref(settings), acc_dev, ldr_dev), "trace_static")
 
     def render(self, scene, settings, first_frame, n_frames, acc_dev, ldr_dev=None, frame_stride=1, sum_mode=0):
         self._chk(lib.mipt_render(self.h, scene.h, C.byref(settings), first_frame, n_frames, frame_stride, sum_mode,

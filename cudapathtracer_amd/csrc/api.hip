@@ -60,6 +60,7 @@ struct mipt_tracer {
     size_t slotDirty[kRing] = {};    // pixels of the slot (from its start) that hold a sample no fold has cleared: the next frame using it clears them first
     bool sampleConsumed = false;     // the most recent frame left no sample behind (fold cleared it / summed straight into acc)
     std::vector<hipEvent_t> freeEvents;      // timing events are pooled: created at the high-water mark, reused, destroyed with the tracer
+    void* staticScratch = nullptr;   // this device's copy of the file-scope `scratch` array (mipt_trace_static)
     hipEvent_t joinEv = nullptr, joinEv2 = nullptr;
     bool pipeBusy = false;           // frames are in flight that `stream` has not been ordered after yet
     bool mainTouched = true;         // something other than a pipelined frame was enqueued on `stream` since aux/fold last waited on it
@@ -93,6 +94,22 @@ struct mipt_buffer {
     void* cpu = nullptr; void* gpu = nullptr; size_t size = 0; int head = MIPT_HEAD_UNINITIALIZED;
     bool ownCpu = false, ownGpu = false;      // false: memory handed in through mipt_buffer_set_*_data (never freed here)
 };
+
+// ---- scratch of the allocation-free entry point (mipt_trace_static) ------------------------------------------------
+// One file-scope device array per GPU the library is loaded on, held until the process ends.  Host code never uses
+// the array's name as an address: mipt_create asks the runtime for this device's copy (hipGetSymbolAddress) and keeps
+// the pointer in the tracer; kernels, memsets and copies take that pointer.
+//   [0, 256)                      64 pixel counters
+//   [256, 256 + 1 MiB)            sample buffer, kStaticMaxPixels x float4
+//   then three SoA wave-stack arrays of kStaticBlocks x 4 waves x cap entries x 16 B (cap = 256 * maxDepth + 256)
+constexpr size_t   kStaticScratchBytes = 32u << 20;
+constexpr uint32_t kStaticMaxPixels = 1u << 16;         // e.g. 256 x 256
+constexpr uint32_t kStaticMaxDepth = 8;
+constexpr int      kStaticBlocks = 64;                  // 256 waves
+constexpr size_t   kStaticSampleOffset = 256;
+constexpr size_t   kStaticStackOffset = kStaticSampleOffset + (size_t)kStaticMaxPixels * 16;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+static_assert(kStaticStackOffset + 3 * (size_t)kStaticBlocks * 4 * (256 * kStaticMaxDepth + 256) * 16 <= kStaticScratchBytes, "static scratch layout");
 
 namespace {
 
@@ -373,6 +390,10 @@ int mipt_create(int device, mipt_tracer** out) {
         if (hipMalloc((void**)&t->counts, 64 * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&t->stats, 40 * sizeof(unsigned long long)) != hipSuccess) {
             mipt_destroy(t); return MIPT_E_NOMEM;
         }
+        // this device's copy of `scratch` (each GPU holds its own, at its own address); `device` is current here
+        void* sp = nullptr;
+        if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp) { mipt_destroy(t); return MIPT_E_HIP; }
+        t->staticScratch = sp;
         hipMemsetAsync(t->stats, 0, 40 * sizeof(unsigned long long), t->stream);
         // A stream gets its hardware queue at its first command, and a process has few of them (GPU_MAX_HW_QUEUES, 4 by
         // default): streams beyond that share queues, and two frames on one queue cannot overlap.  Take the queues of the
@@ -905,6 +926,52 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
 int mipt_trace(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, float* acc_dev, unsigned char* ldr_dev) {
     if (!st) return fail(t, MIPT_E_INVALID, "null settings");
     return mipt_render(t, sc, st, st->frameID, 1, 1, 0, acc_dev, ldr_dev);
+}
+
+// mipt_trace for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid
+// hipMalloc): same contract and same kernels, but every work buffer -- pixel counter, sample buffer, wave stacks --
+// lives in this GPU's `scratch` array, reached through the pointer mipt_create obtained.  No hipMalloc / hipFree /
+// event creation on this path; everything is queued on the tracer's stream.  Limits: viewportWidth * viewportHeight
+// <= 65536, maxDepth <= 8, estimator 0 or 2, integrator 0, rng_mode node, no tile partition.  Calls on one GPU share
+// the array: the parts that must start at zero are cleared per call, and calls that overlap on one GPU (two tracers,
+// or two streams) race.
+int mipt_trace_static(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, float* acc_dev, unsigned char* ldr_dev) {
+    if (!t || !sc || !st || !acc_dev) return fail(t, MIPT_E_INVALID, "null argument");
+    if (sc->t != t) return fail(t, MIPT_E_INVALID, "scene belongs to another tracer");
+    const uint32_t W = st->viewportWidth, H = st->viewportHeight, D = st->maxDepth;
+    if (!W || !H) return fail(t, MIPT_E_INVALID, "empty viewport");
+    if ((uint64_t)W * H > kStaticMaxPixels) return fail(t, MIPT_E_LIMIT, "mipt_trace_static: viewport exceeds 65536 pixels (the static scratch holds one sample buffer of that size)");
+    if (D > kStaticMaxDepth) return fail(t, MIPT_E_LIMIT, "mipt_trace_static: maxDepth exceeds 8 (the static scratch holds 256 wave stacks of 256 * 8 + 256 rays)");
+    if (t->rngMode != MIPT_RNG_NODE || t->integrator != 0 || t->tileParts > 1 || t->countPixelRays || (t->estimator != 0 && t->estimator != 2))
+        return fail(t, MIPT_E_INVALID, "mipt_trace_static: needs integrator 0, rng_mode node, estimator 0 or 2, no tile partition, no per-pixel ray counting");
+    if (!t->staticScratch) return fail(t, MIPT_E_HIP, "mipt_trace_static: no static scratch on this device");
+    if (use(t)) return MIPT_E_HIP;
+    const uint32_t npix = W * H;
+    unsigned char* base = (unsigned char*)t->staticScratch;
+    uint32_t* counters = (uint32_t*)base;
+    float* sample = (float*)(base + kStaticSampleOffset);
+    const uint32_t wcap = 256u * std::max<uint32_t>(D, 1u) + 256u;
+    const size_t arr = (size_t)kStaticBlocks * 4 * wcap * sizeof(float4);
+    HIPCHK(t, hipMemsetAsync(counters, 0, 256, t->stream));
+    HIPCHK(t, hipMemsetAsync(sample, 0, (size_t)npix * 16, t->stream));
+    const FrameDev F = make_frame(*st, st->frameID);
+    if (D >= 1) {
+        StackArgs SA;
+        SA.S = sc->dev; SA.F = F;
+        SA.stack.a = (float4*)(base + kStaticStackOffset); SA.stack.b = (float4*)(base + kStaticStackOffset + arr); SA.stack.c = (float4*)(base + kStaticStackOffset + 2 * arr);
+        SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes;
+        SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (wavestack_scene_in_lds(sc->dev) ? 8 : 24));
+        SA.pixCounter = counters; SA.nee = (uint32_t)t->estimator; SA.xcdBands = 0;
+        SA.sample = sample; SA.pixelRays = nullptr; SA.stats = t->stats; SA.pix0 = 0; SA.npix = npix; SA.band = Band{ 0u, 1u, 0u }; SA.alphaOne = 0;
+        launch_wavestack(SA, std::min<int>((int)((npix + 255) / 256), kStaticBlocks), t->stream);
+        t->launches++;
+    }
+    const float weight = (float)(1.0 / (st->frameID + 1.0));       // CUDATracerProg.cu:878
+    launch_accumulate(sample, acc_dev, ldr_dev, weight, 0, 0, Band{ 0u, 1u, 0u }, 0, npix, t->stream);
+    HIPCHK(t, hipGetLastError());
+    t->sampleConsumed = true;          // mipt_last_sample reads the tracer's own sample buffers, not the scratch
+    t->frames++;
+    return MIPT_OK;
 }
 
 int mipt_tonemap(mipt_tracer* t, const float* acc_dev, float scale, uint32_t n_pixels, unsigned char* ldr_dev) {

@@ -176,6 +176,16 @@ int  mipt_trace(mipt_tracer*, mipt_scene*, const mipt_settings*, float* acc_dev,
  * multi-GPU sample striding where the caller reduces and scales). frame_stride lets rank r render r, r+G, ... */
 int  mipt_render(mipt_tracer*, mipt_scene*, const mipt_settings*, uint32_t first_frame, uint32_t n_frames,
                  uint32_t frame_stride, int sum_mode, float* acc_dev, unsigned char* ldr_dev);
+/* mipt_trace for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
+ * contract, same kernels and same result as mipt_trace (radiance up to the order of the fp32 adds into a pixel), but
+ * every work buffer (pixel counter, sample buffer, 256 wave stacks) lives in a 32 MiB file-scope device array that each
+ * GPU the library runs on holds until the process ends; the call makes no hipMalloc / hipFree / event creation and
+ * queues everything on the tracer's stream.  Limits (MIPT_E_LIMIT beyond them): viewportWidth * viewportHeight <= 65536,
+ * maxDepth <= 8; needs integrator 0, rng_mode node, estimator 0 or 2, no tile partition, count_pixel_rays off.  All
+ * calls on one GPU share the array (what must start at zero is cleared per call): calls that overlap on one GPU --
+ * two tracers, or a caller-supplied stream running beside another -- race. */
+int  mipt_trace_static(mipt_tracer*, mipt_scene*, const mipt_settings*, float* acc_dev, unsigned char* ldr_dev);
 /* accumulate-free tonemap of an accumulation buffer (scale applied first): CUDATracerProg.cu:908-919 */
 int  mipt_tonemap(mipt_tracer*, const float* acc_dev, float scale, uint32_t n_pixels, unsigned char* ldr_dev);
 /* radiance of the last frame traced, before accumulation (w*h*3 floats) and its per-pixel ray counts; for parity tests.
