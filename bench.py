@@ -4,18 +4,28 @@
   python bench.py --gpus 1 --steps 8 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step = one frame (1 spp) of the workload per GPU.  Default workload = BASELINE.json configs[1]: Cornell box,
-1920x1080, 8 bounces (`--workload default` = configs[2]: DefaultScene + synthetic HDRI, 12 bounces; `--workload grid`
-= the configs[4] stand-in: 10 M-triangle displaced grid, 3840x2160, 4 bounces -- the HBM-stressing case).  With N > 1 the
-scene is replicated, rank r renders frame indices r, r+N, ... into a private sum buffer (weak scaling: one frame per
-GPU per step) and ONE RCCL reduce of the accumulation buffers closes the timed region.
+A step = one frame (1 spp) of the workload per GPU.  The headline workload (`metric`, `value`, `ms_per_step`, `roofline`,
+`cpu_baseline`) is BASELINE.json configs[1]: Cornell box, 1920x1080, 8 bounces.  BASELINE's metric is quoted on
+"Cornell + HDRI scene", so the same run then measures, the same way, configs[2] (DefaultScene + synthetic HDRI, 1080p, 12
+bounces) and the configs[4] stand-in (10 M-triangle displaced grid, 3840x2160, 4 bounces: the HBM-stressing case) and
+attaches them under `workloads` in the ONE JSON line.  `--workload cornell|default|grid` runs just that one as the headline.
 
-Prints ONE JSON line on rank 0: whole-job Mrays/s (closest-hit extension rays; the reference traces no shadow rays)
-plus spp/s, a roofline object for the dominant kernel (k_wavestack, the persistent extend+shade kernel) and, at
-N = 1, the CPU oracle timed on this host as a reported baseline.
+Timed region: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks.
+Because K frames of a cache-resident scene take ~0.1 s, that K-step measurement is repeated until the repeats add up to
+`--min-seconds` (1 s) and the MEDIAN repeat is reported (`repeats`, `timed_region_s` say how many and how long).
+With N > 1 the scene is replicated, rank r renders frame indices r, r+N, ... into a private sum buffer (weak scaling:
+one frame per GPU per step) and ONE RCCL reduce of the accumulation buffers closes every timed repeat.
+
+Roofline (per workload, dominant kernel k_wavestack): a scene whose BVH + triangles fit the 32 MiB of L2 is bound by
+VALU issue, not HBM -- `bound: "valu"`, achieved = ALGORITHMIC lane-operations per launch (per node visit,
+per triangle test, per shade, counts from the CPU oracle on the same flat BVH) / the launch's HIP-event duration, peak =
+the guide's fp32 vector rate.  The grid keeps `bound: "hbm"` with SURVEY 8d's algorithmic bytes per ray.  Both fractions
+are at most 1 by construction and both sub-objects (`valu`, `hbm`) are always attached.
 """
 import argparse
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -25,7 +35,22 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+# fp32 vector peak of the guide: 157.3 TFLOP/s = 78.65 T fused multiply-adds per second = lane-operations per second when
+# every instruction is a packed FMA (v_pk_fma_f32).  Plain wave64 VALU instructions issue at a quarter of a SIMD's cycles
+# (profiles/r2/issue_calibration.jsonl: 0.22-0.25 v_fma_f32 per SIMD-cycle at 1..8 waves per SIMD), i.e. half of this.
+VALU_PEAK_TLOPS = 78.65
+VALU_ISSUE_PEAK_TLOPS = 39.3  # 1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes: what un-packed instructions can reach (measured 35-39)
+# algorithmic VALU lane-operations: BVH2 node visit 46 (two slab tests: 12 FMA + 2 x (3 min + 3 max) + compares
+# and selects); Moeller-Trumbore 45; one shade 150.  A quantised 4-wide visit by the same counting: 9 (exponent scales,
+# origin) + 4 x (6 byte->float + 6 FMA + 3 min + 3 max + 2 clamps + 2 compare/select) + 10 (5-exchange sort on keys) = 107
+OPS_NODE_BVH2, OPS_NODE_Q4, OPS_TRI, OPS_SHADE = 46.0, 107.0, 45.0, 150.0
+
+WORKLOADS = {          # name -> (BASELINE.json config, width, height, maxDepth)
+    "cornell": ("configs[1]", 1920, 1080, 8),
+    "default": ("configs[2]", 1920, 1080, 12),
+    "grid": ("configs[4] stand-in", 3840, 2160, 4),
+}
 
 
 def parse():
@@ -33,25 +58,27 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=32)
     p.add_argument("--warmup", type=int, default=4)
-    p.add_argument("--workload", default="cornell", choices=["cornell", "default", "grid"])
+    p.add_argument("--workload", default="all", choices=["all", "cornell", "default", "grid"],
+                   help="all (default): cornell is the headline, default and grid are attached under `workloads`")
+    p.add_argument("--min-seconds", type=float, default=1.0, help="the K-step measurement is repeated until the repeats add up to this")
     p.add_argument("--width", type=int, default=0, help="0 = 1920 (cornell, default) or 3840 (grid)")
     p.add_argument("--height", type=int, default=0, help="0 = 1080 (cornell, default) or 2160 (grid)")
     p.add_argument("--depth", type=int, default=0, help="0 = 8 for cornell, 12 for default, 4 for grid (BASELINE.json)")
     p.add_argument("--grid-n", type=int, default=2236, help="grid workload: n x n quads = 2 n^2 triangles (2236 -> 10.0 M)")
-    p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU oracle budget (0 disables cpu_baseline)")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU oracle budget of the headline workload (0 disables cpu_baseline); the attached workloads get half")
     p.add_argument("--tile-pixels", type=int, default=0)
     p.add_argument("--integrator", type=int, default=0, help="0 persistent wave stacks (default), 1 level-synchronous queues")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (default); gloo = rehearsal of the N>1 flow through host memory")
     p.add_argument("--node-width", type=int, default=0, help="BVH node layout: 0 library default, 2 fp32 BVH2, 4 quantised 4-wide")
     p.add_argument("--pipeline", type=int, default=1, help="1 (default): consecutive frames alternate between two streams so a frame's tail overlaps the next frame; 0: one stream")
     p.add_argument("--estimator", type=int, default=0, help="0 the reference's estimator (default, the parity configuration); 1 env-map / emitter sampling with occlusion rays; 2 VNDF-sampled specular + cosine-weighted diffuse lobes; 3 both")
-    p.add_argument("--traffic-gb", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC run (GB)")
+    p.add_argument("--option", action="append", default=[], help="key=value passed to mipt_set_option (tuning experiments)")
     return p.parse_args()
 
 
 def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0):
-    """Times the CPU oracle (same flat BVH, node-keyed RNG) on evenly spaced rows of frame 0 and returns its rate
-    and the mean node visits / triangle tests per non-primary ray (the figures B_ray is computed from)."""
+    """Times the CPU oracle (same flat BVH, node-keyed RNG) on a bounded sample of the workload and returns its rate and
+    the mean node visits / triangle tests per ray (the figures the algorithmic bytes and operations are computed from)."""
     from oracle import orc                      # cpu_baseline leg only: checker / reported baseline
     import ctypes as C
     o = orc.Scene(data)
@@ -65,48 +92,266 @@ def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0)
         s.maxDepth = depth
         tot = dict(rays=0, nodes=0, tris=0, hits=0, sec=0.0)
         acc = np.zeros((H, W, 4), np.float32)
-        for y in rows:
+        for y in rows:      # bands of BAND rows: enough 64-pixel work items per call to keep 16 threads busy
             t0 = time.perf_counter()
-            r = o.render(s, orc.ISECT_FLAT, orc.RNG_NODE, orc.MATH_DET, 0, 1, rect=(0, y, W, y + 1), acc=acc, want_ldr=False, nthreads=threads)
+            r = o.render(s, orc.ISECT_FLAT, orc.RNG_NODE, orc.MATH_DET, 0, 1, rect=(0, y, W, min(y + BAND, H)), acc=acc, want_ldr=False, nthreads=threads)
             tot["sec"] += time.perf_counter() - t0
             st = r["stats"]
             tot["rays"] += st.rays; tot["nodes"] += st.node_visits; tot["tris"] += st.tri_tests; tot["hits"] += st.hits
         return tot
 
+    BAND = 8
     probe_rows = [H // 3, H // 2]
     probe = run(probe_rows, settings.maxDepth)
-    per_row = max(probe["sec"] / len(probe_rows), 1e-4)
-    n_rows = int(min(H, max(4, seconds / per_row)))
+    per_row = max(probe["sec"] / (len(probe_rows) * BAND), 1e-5)
+    n_rows = int(min(H, max(BAND, seconds / per_row)))
     if n_rows >= H:
         # the whole frame fits the budget: time whole frames (one call each, no per-row call overhead), as many as fit
         n_frames = int(min(16, max(1, seconds / (per_row * H))))
-
-        def run_frames(depth):
-            s = pt.Settings()
-            C.memmove(C.addressof(s), C.addressof(settings), C.sizeof(pt.Settings))
-            s.maxDepth = depth
-            t0 = time.perf_counter()
-            r = o.render(s, orc.ISECT_FLAT, orc.RNG_NODE, orc.MATH_DET, 0, n_frames, want_ldr=False, nthreads=threads)
-            st = r["stats"]
-            return dict(rays=st.rays, nodes=st.node_visits, tris=st.tri_tests, hits=st.hits, sec=time.perf_counter() - t0)
-        full, prim = run_frames(settings.maxDepth), run_frames(1)
+        s = pt.Settings()
+        C.memmove(C.addressof(s), C.addressof(settings), C.sizeof(pt.Settings))
+        t0 = time.perf_counter()
+        r = o.render(s, orc.ISECT_FLAT, orc.RNG_NODE, orc.MATH_DET, 0, n_frames, want_ldr=False, nthreads=threads)
+        st = r["stats"]
+        full = dict(rays=st.rays, nodes=st.node_visits, tris=st.tri_tests, hits=st.hits, sec=time.perf_counter() - t0)
         desc = f"frames 0..{n_frames - 1} of the same workload, whole"
     else:
-        rows = sorted(set(int(round(i * (H - 1) / max(n_rows - 1, 1))) for i in range(n_rows)))
+        n_bands = max(1, n_rows // BAND)
+        rows = sorted(set(int(round(i * (H - BAND) / max(n_bands - 1, 1))) // BAND * BAND for i in range(n_bands)))
         full = run(rows, settings.maxDepth)
-        prim = run(rows, 1)
-        desc = f"{len(rows)} evenly spaced rows of frame 0 of the same workload"
-    sec_rays = max(full["rays"] - prim["rays"], 1)
+        desc = f"{len(rows)} evenly spaced bands of {BAND} rows of frame 0 of the same workload"
+    rays = max(full["rays"], 1)
     return dict(desc=desc, rays=full["rays"], sec=full["sec"], mrays=full["rays"] / full["sec"] / 1e6,
-                n_node=(full["nodes"] - prim["nodes"]) / sec_rays, n_tri=(full["tris"] - prim["tris"]) / sec_rays,
-                miss_frac=1.0 - (full["hits"] - prim["hits"]) / sec_rays,
-                n_node_all=full["nodes"] / max(full["rays"], 1), n_tri_all=full["tris"] / max(full["rays"], 1),
-                miss_all=1.0 - full["hits"] / max(full["rays"], 1))
+                n_node=full["nodes"] / rays, n_tri=full["tris"] / rays, miss=1.0 - full["hits"] / rays)
 
 
 def dbg(msg):
     if os.environ.get("BENCH_DEBUG"):
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
+def source_sha16():
+    """Hash of the kernel + host sources: PMC figures measured on another build are not attached to this one."""
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "kernels.h", "device_math.h", "api.hip", "bvh_builder.cpp"):
+        with open(os.path.join(ROOT, "cudapathtracer_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_for(workload, default_config):
+    """HBM bytes per launch etc. from the committed rocprofv3 --pmc passes of this same command, tagged with where they
+    come from; None when they were measured on other sources or another configuration (never silently stale)."""
+    if not default_config:
+        return None
+    for rnd in ("r2", "r1"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+        try:
+            pj = json.load(open(path))
+        except Exception:
+            continue
+        meta = pj.get("_meta", {})
+        if meta.get("source_sha16") != source_sha16() or workload not in pj:
+            continue
+        e = dict(pj[workload])
+        e["source"] = f"profiles/{rnd}/pmc_traffic.json ({meta.get('collected', 'rocprofv3 --pmc')}; sources {meta.get('source_sha16')})"
+        return e
+    return None
+
+
+def build_scene(pt, a, name, t, rank, multi, dist):
+    depth = a.depth or WORKLOADS[name][3]
+    W = a.width or WORKLOADS[name][1]
+    H = a.height or WORKLOADS[name][2]
+    if name == "cornell":
+        data = pt.builtin_scene(0)
+        cam = pt.make_camera(**pt.CORNELL_CAMERA)
+    elif name == "default":
+        data = pt.builtin_scene(1, pt.synthetic_sky(2048, 1024, 0x5EED))
+        cam = pt.make_camera(**pt.DEFAULT_CAMERA)
+    else:
+        # BASELINE.json configs[4] stand-in (SURVEY 8d C5): displaced grid, one diffuse material, synthetic HDRI
+        v, i = pt.grid_mesh(a.grid_n, 8.0, 1.0, 1)
+        sky = pt.SkyLight(); sky.color[:] = (0.98, 0.97, 0.99); sky.dir[:] = (-0.577, -0.577, -0.577); sky.intensity = 5
+        data = pt.SceneData([(v, i, pt.make_material(color=(0.8, 0.8, 0.8), roughness=0.5, metallic=0.0, opacity=1.0, n=2.5))],
+                            sky, pt.synthetic_sky(2048, 1024, 0x5EED))
+        cam = pt.make_camera((-7.0, 4.0, 0.0), 0.0, 2.0, float(np.float32(np.pi / 3)))
+    settings = pt.make_settings(cam, W, H, depth)
+    if name == "grid" and multi:
+        # 10 M triangles: rank 0 builds the BVH and writes the cache file, the others load it instead of building eight times
+        cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mipt_bench_grid{a.grid_n}_w{a.node_width}.bvh")
+        sc = pt.Scene(t, data, node_width=a.node_width, bvh_cache=cache) if rank == 0 else None
+        dist.barrier()
+        if rank != 0:
+            sc = pt.Scene(t, data, node_width=a.node_width, bvh_cache=cache)
+    else:
+        sc = pt.Scene(t, data, node_width=a.node_width)
+    return data, settings, sc, W, H, depth
+
+
+def run_workload(name, a, ctx, cpu_seconds):
+    """Measures one workload; returns the dict of its figures (rank 0) or None (other ranks)."""
+    pt, ptdist, torch, dist, t, dev = ctx["pt"], ctx["ptdist"], ctx["torch"], ctx["dist"], ctx["t"], ctx["dev"]
+    rank, world, multi = ctx["rank"], ctx["world"], ctx["multi"]
+    data, settings, sc, W, H, depth = build_scene(pt, a, name, t, rank, multi, dist)     # BVH built before any timed region
+    dbg(f"{name}: scene uploaded")
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    ldr = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    sum_mode = 1 if multi else 0
+    cdev = dev if a.backend == "nccl" else torch.device("cpu")
+
+    def step(i):   # global step index -> this rank's frame
+        t.render(sc, settings, i * world + rank, 1, acc.data_ptr(), None if sum_mode else ldr.data_ptr(), 1, sum_mode)
+
+    def barrier():
+        t.synchronize()
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+
+    def close(n_steps):   # the path's one exchange step: reduce the sum buffers onto rank 0, scale, tonemap
+        mean = ptdist.reduce_accumulation(acc if a.backend == "nccl" else acc.cpu(), n_steps * world, dst=0)
+        if rank == 0:
+            mean = mean.to(dev)
+            torch.cuda.synchronize()        # torch's stream produced `mean`; the tracer reads it on its own stream
+            t.tonemap(mean.data_ptr(), 1.0, W * H, ldr.data_ptr())
+
+    for i in range(a.warmup):
+        step(i)
+    if multi:   # the whole closing sequence once, untimed (first use of a torch kernel or an RCCL communicator costs tens of ms)
+        t.synchronize()
+        close(max(a.warmup, 1))
+        acc.zero_()
+    barrier()
+    t.reset_counters()
+    t.set_option("profile_levels", 1)
+
+    def timed_repeat(first_step):
+        if multi:
+            acc.zero_()
+        rays0 = t.counters()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(first_step + i)
+        t.synchronize()
+        if multi:
+            close(a.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        c = t.counters()
+        v = torch.tensor([dt, 0.0, 0.0], dtype=torch.float64, device=cdev)
+        r = torch.tensor([float(c.rays - rays0.rays), float(c.shadow_rays - rays0.shadow_rays)], dtype=torch.float64, device=cdev)
+        if multi:
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        return float(v[0].item()), float(r[0].item()), float(r[1].item())
+
+    reps = [timed_repeat(a.warmup)]
+    # every rank sees the same (max-reduced) first duration, so every rank runs the same number of repeats
+    n_rep = int(min(64, max(1, math.ceil(a.min_seconds / max(reps[0][0], 1e-6)))))
+    for k in range(1, n_rep):
+        reps.append(timed_repeat(a.warmup + k * a.steps))
+    t.set_option("profile_levels", 0)
+    order = sorted(range(len(reps)), key=lambda k: reps[k][0])
+    dt, total_rays, total_shadow = reps[order[len(order) // 2]]            # the median repeat
+    timed_s = sum(r[0] for r in reps)
+    cnt = t.counters()
+    prof = t.level_profile()
+    out = None
+    if rank == 0:
+        nodes, refs = sc.bvh()
+        nn, nr = len(nodes), len(refs)
+        launches_total = n_rep * a.steps
+        if a.integrator == 0:    # one k_wavestack launch per frame traces every ray of the frame
+            lds = sc.bvh_width == 2 and nn * 4 + nr * 3 <= 256          # <LDS scene, 4-wide nodes, light sampling, estimator-2 lobes>
+            kernel_name = "mipt::k_wavestack<%s, %s, %s, %s>" % tuple("true" if x else "false" for x in (lds, sc.bvh_width == 4, a.estimator in (1, 3), a.estimator >= 2))
+            sec_rays, sec_ms, sec_launches = float(cnt.rays), prof.ms[0], prof.launches[0]
+        else:                    # k_level<false,*> launches carry the non-primary levels
+            kernel_name = "mipt::k_level<false,*>"
+            sec_rays = sum(prof.rays[k] for k in range(1, 32))
+            sec_ms = sum(prof.ms[k] for k in range(1, 32))
+            sec_launches = sum(prof.launches[k] for k in range(1, 32))
+        cpu = None
+        if cpu_seconds > 0:
+            threads = min(os.cpu_count() or 1, 16)
+            cpu = oracle_sample(pt, data, (nodes, refs), sc.bvh_width, settings, cpu_seconds if world == 1 else min(cpu_seconds, 3.0), threads, a.estimator)
+        default_config = (W, H, depth) == WORKLOADS[name][1:] and (name != "grid" or a.grid_n == 2236) and not a.node_width and not a.estimator and not a.option and a.integrator == 0 and a.pipeline == 1
+        pmc = pmc_for(name, default_config)
+        working_set = nn * 64 + nr * 48
+        roof = None
+        if cpu is not None and sec_ms > 0 and sec_launches > 0:
+            n_node, n_tri, miss = cpu["n_node"], cpu["n_tri"], cpu["miss"]
+            rays_launch = sec_rays / sec_launches
+            # Duration of one launch.  Pipelined launches overlap pairwise (two streams), so a launch's own event window
+            # -- and rocprofv3's kernel duration -- includes the time it shares the GPU with, or waits for CUs behind, its
+            # neighbour: the windows add up to more than the time the kernel occupied the GPU.  The effective duration is
+            # the HIP-event span of the timed launches (first start to last end, per timed repeat) over their number;
+            # scripts/kt_steady.py computes the same two figures from the rocprofv3 kernel trace.
+            window_s = sec_ms / sec_launches * 1e-3
+            launch_s = (cnt.kernel_span_ms / sec_launches * 1e-3) if (a.integrator == 0 and cnt.kernel_span_ms > 0) else window_s
+            wall_s = dt / a.steps
+            # ---- HBM: SURVEY 8(d): B_ray = 64*N_node + 48*N_tri + 64 (+12 per env-map miss)
+            b_ray = 64.0 * n_node + 48.0 * n_tri + 64.0 + (12.0 * miss if data.env is not None else 0.0)
+            hbm = {"achieved": round(rays_launch * b_ray / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(rays_launch * b_ray / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                   "achieved_wall": round(rays_launch * b_ray / wall_s / 1e9, 1),
+                   "bytes_per_ray": round(b_ray, 1), "algorithmic_gb_per_launch": round(rays_launch * b_ray / 1e9, 2),
+                   "traffic_gb_per_launch": None if not pmc else round(pmc["hbm_gb_per_launch"], 2),
+                   "traffic_frac": None if not pmc else round(pmc["hbm_gb_per_launch"] / launch_s / HBM_PEAK_GBS, 4)}
+            # ---- VALU: algorithmic lane-operations per ray (SURVEY 8d), shades = rays that spawned children = (rays - primaries) / 2
+            shades = max(0.0, (rays_launch - W * H) / 2.0) / rays_launch
+            c_node = OPS_NODE_Q4 if sc.bvh_width == 4 else OPS_NODE_BVH2
+            ops_ray = c_node * n_node + OPS_TRI * n_tri + OPS_SHADE * shades
+            valu_ach = rays_launch * ops_ray / launch_s / 1e12
+            valu = {"achieved": round(valu_ach, 2), "peak": VALU_PEAK_TLOPS, "unit": "T lane-op/s",
+                    "frac": round(valu_ach / VALU_PEAK_TLOPS, 4),
+                    "achieved_wall": round(rays_launch * ops_ray / wall_s / 1e12, 2),
+                    "frac_of_unpacked_issue_peak": round(valu_ach / VALU_ISSUE_PEAK_TLOPS, 4), "unpacked_issue_peak": VALU_ISSUE_PEAK_TLOPS,
+                    "ops_per_ray": round(ops_ray, 1), "ops_per_node_visit": c_node, "ops_per_triangle_test": OPS_TRI, "ops_per_shade": OPS_SHADE,
+                    "shades_per_ray": round(shades, 4),
+                    "peak_source": "MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector = 78.65 T FMA/s (packed); un-packed issue measured by k_test_issue, profiles/r2/issue_calibration.jsonl"}
+            if pmc:
+                valu["pmc"] = {k: pmc[k] for k in ("valu_busy", "lane_utilisation", "wait_frac", "l2_hit", "executed_lane_ops_per_ray") if k in pmc}
+            bound = "hbm" if working_set > (32 << 20) else "valu"
+            head = hbm if bound == "hbm" else valu
+            assert 0.0 < head["frac"] <= 1.0, f"roofline fraction {head['frac']} of {name} is not a fraction"
+            roof = {"bound": bound, "achieved": head["achieved"], "peak": head["peak"], "unit": head["unit"], "frac": head["frac"],
+                    "traffic": hbm["traffic_gb_per_launch"], "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
+                    "traffic_source": pmc["source"] if pmc else "none for this build/configuration (scripts/profile_all.sh regenerates profiles/r2/pmc_traffic.json)",
+                    "kernel": kernel_name, "n_node_per_ray": round(n_node, 3), "n_tri_per_ray": round(n_tri, 3),
+                    "rays_per_launch": round(rays_launch, 1), "avg_launch_ms": round(launch_s * 1e3, 4), "avg_launch_window_ms": round(window_s * 1e3, 4), "launches": int(sec_launches),
+                    "avg_launch_ms_is": "HIP-event span of the timed launches / launches (launches overlap pairwise when pipelined); avg_launch_window_ms = mean of the launches' own event windows",
+                    # consecutive frames run on two streams, so a launch's event window includes the time it shares the GPU
+                    # with (or queues behind) its neighbour; the wall figures divide the timed region by the launches instead
+                    "frames_pipelined": bool(a.pipeline and a.integrator == 0), "wall_ms_per_launch": round(wall_s * 1e3, 4),
+                    "working_set_mb": round(working_set / 1e6, 2),
+                    "bound_reason": ("BVH + triangles exceed the 32 MiB of L2 (and the 256 MiB Infinity Cache): node / triangle fetches go to HBM" if bound == "hbm" else
+                                     "BVH + triangles fit LDS / L2: algorithmic bytes are served on-chip, VALU issue binds (PMC: valu_busy)"),
+                    "valu": valu, "hbm": hbm}
+        out = {
+            "value": round(total_rays / dt / 1e6, 1), "unit": "Mrays/s", "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "repeats": n_rep, "timed_region_s": round(timed_s, 3), "ms_per_step_min_max": [round(reps[order[0]][0] / a.steps * 1e3, 3), round(reps[order[-1]][0] / a.steps * 1e3, 3)],
+            "config": {"workload": f"{name}_{W}x{H}_{depth}bounce_1spp_per_gpu_step" + (f"_n{a.grid_n}" if name == "grid" else ""), "baseline_config": WORKLOADS[name][0],
+                       "width": W, "height": H, "max_depth": depth,
+                       "triangles": data.triangle_count, "bvh": "sbvh" + ("-q4" if sc.bvh_width == 4 else ""), "rng": "node", "integrator": "wave-stacks" if a.integrator == 0 else "level-queues", "parallelism": f"sample-striding x{world}",
+                       "env_map": None if data.env is None else "synthetic 2048x1024"},
+            "spp_per_s": round(a.steps * world / dt, 3), "rays_per_step_per_gpu": round(total_rays / a.steps / world, 1),
+            "shadow_rays": round(total_shadow / a.steps / world, 1), "kernel_ms_per_step": round(cnt.kernel_ms / max(launches_total, 1), 3),
+            "accumulate_ms": round(prof.accumulate_ms / max(launches_total, 1), 3),
+            "roofline": roof,
+        }
+        if a.integrator:
+            out["level_ms"] = [round(prof.ms[k] / launches_total, 3) for k in range(depth)]
+            out["level_mrays"] = [round(prof.rays[k] / launches_total / 1e6, 2) for k in range(depth)]
+        if cpu is not None and world == 1:
+            out["cpu_baseline"] = {"value": round(cpu["mrays"], 2), "unit": "Mrays/s", "cores": min(os.cpu_count() or 1, 16), "kind": "port",
+                                   "sample": f"{cpu['desc']} ({cpu['rays']} rays, {cpu['sec']:.1f} s), same flat BVH"}
+    del acc, ldr
+    sc.close()
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -141,173 +386,28 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-
-    depth = a.depth or {"cornell": 8, "default": 12, "grid": 4}[a.workload]
-    W = a.width or (3840 if a.workload == "grid" else 1920)
-    H = a.height or (2160 if a.workload == "grid" else 1080)
-    if a.workload == "cornell":
-        data = pt.builtin_scene(0)
-        cam = pt.make_camera(**pt.CORNELL_CAMERA)
-    elif a.workload == "default":
-        data = pt.builtin_scene(1, pt.synthetic_sky(2048, 1024, 0x5EED))
-        cam = pt.make_camera(**pt.DEFAULT_CAMERA)
-    else:
-        # BASELINE.json configs[4] stand-in: displaced grid, one diffuse material, synthetic HDRI
-        v, i = pt.grid_mesh(a.grid_n, 8.0, 1.0, 1)
-        sky = pt.SkyLight(); sky.color[:] = (0.98, 0.97, 0.99); sky.dir[:] = (-0.577, -0.577, -0.577); sky.intensity = 5
-        data = pt.SceneData([(v, i, pt.make_material(color=(0.8, 0.8, 0.8), roughness=0.5, metallic=0.0, opacity=1.0, n=2.5))],
-                            sky, pt.synthetic_sky(2048, 1024, 0x5EED))
-        cam = pt.make_camera((-7.0, 4.0, 0.0), 0.0, 2.0, float(np.float32(np.pi / 3)))
-    settings = pt.make_settings(cam, W, H, depth)
-
-    dbg("scene data ready")
     if a.tile_pixels:
         t.set_option("tile_pixels", a.tile_pixels)
     t.set_option("integrator", a.integrator)
     t.set_option("estimator", a.estimator)
     t.set_option("pipeline_frames", a.pipeline)
-    if a.workload == "grid" and multi:
-        # 10 M triangles: rank 0 builds the BVH and writes the cache file, the others load it instead of building eight times
-        cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mipt_bench_grid{a.grid_n}_w{a.node_width}.bvh")
-        sc = pt.Scene(t, data, node_width=a.node_width, bvh_cache=cache) if rank == 0 else None
-        dist.barrier()
-        if rank != 0:
-            sc = pt.Scene(t, data, node_width=a.node_width, bvh_cache=cache)
-    else:
-        sc = pt.Scene(t, data, node_width=a.node_width)
-    dbg("scene uploaded")
-    acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-    ldr = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-    sum_mode = 1 if multi else 0
-
-    def step(i):   # global step index -> this rank's frame
-        frame = i * world + rank
-        t.render(sc, settings, frame, 1, acc.data_ptr(), None if sum_mode else ldr.data_ptr(), 1, sum_mode)
-
-    def barrier():
-        t.synchronize()
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-
-    for i in range(a.warmup):
-        step(i)
-    dbg("warm-up frames queued")
-    if multi:   # warm the RCCL path too, then start the timed run from a clean sum buffer
-        t.synchronize()
-        dbg("warm-up frames done")
-        # the whole closing sequence once, untimed: reduce, scale, tonemap (first use of a torch kernel or an RCCL
-        # communicator costs tens of milliseconds)
-        warm = ptdist.reduce_accumulation(acc.clone() if a.backend == "nccl" else acc.cpu(), max(a.warmup, 1) * world, dst=0)
-        if rank == 0:
-            warm = warm.to(dev)
-            torch.cuda.synchronize()
-            t.tonemap(warm.data_ptr(), 1.0, W * H, ldr.data_ptr())
-        dbg("warm-up reduce done")
-        acc.zero_()
-    dbg("warm-up done")
-    barrier()
-    t.reset_counters()
-    t.set_option("profile_levels", 1)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i)
-    t.synchronize()
-    t_frames = time.perf_counter() - t0
-    if multi:   # the path's one exchange step: reduce the sum buffers onto rank 0, scale, tonemap
-        mean = ptdist.reduce_accumulation(acc if a.backend == "nccl" else acc.cpu(), a.steps * world, dst=0)
-        if rank == 0:
-            mean = mean.to(dev)
-            torch.cuda.synchronize()        # torch's stream produced `mean`; the tracer reads it on its own stream
-            t.tonemap(mean.data_ptr(), 1.0, W * H, ldr.data_ptr())
-    barrier()
-    dt = time.perf_counter() - t0
-    dbg(f"timed region done: frames {t_frames * 1e3:.2f} ms, closing reduce + tonemap + barrier {(dt - t_frames) * 1e3:.2f} ms")
-    t.set_option("profile_levels", 0)
-
-    cnt = t.counters()
-    prof = t.level_profile()
-    cdev = dev if a.backend == "nccl" else torch.device("cpu")
-    rays = torch.tensor([float(cnt.rays), float(cnt.shadow_rays)], dtype=torch.float64, device=cdev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    if multi:
-        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_rays, total_shadow, dt = float(rays[0].item()), float(rays[1].item()), float(tmax.item())
-
+    for kv in a.option:
+        k, v = kv.split("=")
+        t.set_option(k, int(v))
+    ctx = dict(pt=pt, ptdist=ptdist, torch=torch, dist=dist, t=t, dev=dev, rank=rank, world=world, multi=multi)
+    names = ["cornell", "default", "grid"] if a.workload == "all" else [a.workload]
+    head = run_workload(names[0], a, ctx, a.cpu_seconds)
+    extra = {}
+    for n in names[1:]:
+        extra[n] = run_workload(n, a, ctx, a.cpu_seconds / 2)
     if rank == 0:
-        nn, nr = (len(x) for x in sc.bvh())
-        if a.integrator == 0:    # one k_wavestack launch per frame traces every ray of the frame
-            lds = sc.bvh_width == 2 and nn * 4 + nr * 3 <= 256          # <LDS scene, 4-wide nodes, light sampling>
-            kernel_name = "mipt::k_wavestack<%s, %s, %s, %s>" % tuple("true" if x else "false" for x in (lds, sc.bvh_width == 4, a.estimator in (1, 3), a.estimator >= 2))
-            sec_rays, sec_ms, sec_launches = float(cnt.rays), prof.ms[0], prof.launches[0]
-        else:                    # k_level<false,*> launches carry the non-primary levels
-            kernel_name = "mipt::k_level<false,*>"
-            sec_rays = sum(prof.rays[k] for k in range(1, 32))
-            sec_ms = sum(prof.ms[k] for k in range(1, 32))
-            sec_launches = sum(prof.launches[k] for k in range(1, 32))
-        cpu = None
-        n_node = n_tri = miss = None
-        if a.cpu_seconds > 0:
-            threads = min(os.cpu_count() or 1, 16)
-            cpu = oracle_sample(pt, data, sc.bvh(), sc.bvh_width, settings, a.cpu_seconds if world == 1 else min(a.cpu_seconds, 3.0), threads, a.estimator)
-            n_node, n_tri, miss = cpu["n_node"], cpu["n_tri"], cpu["miss_frac"]
-            if a.integrator == 0:
-                n_node, n_tri, miss = cpu["n_node_all"], cpu["n_tri_all"], cpu["miss_all"]
-        traffic = a.traffic_gb
-        pmc = {}
-        default_size = (W, H) == ((3840, 2160) if a.workload == "grid" else (1920, 1080)) and (a.workload != "grid" or a.grid_n == 2236)
-        if traffic is None and a.integrator == 0 and default_size and not a.depth and not a.node_width and not a.estimator:
-            # HBM bytes per launch from the committed PMC passes of this same command (scripts/pmc_passes.sh;
-            # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, plus WRITE_SIZE)
-            try:
-                pj = json.load(open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")))
-                traffic = round(pj[a.workload]["hbm_gb_per_launch"], 2)
-                pmc = {k: pj[a.workload][k] for k in ("valu_busy", "lane_utilisation", "wait_frac", "l2_hit") if k in pj[a.workload]}
-            except Exception:
-                traffic = None
-        roof = None
-        if n_node is not None and sec_ms > 0:
-            # B_ray = 64*N_node + 48*N_tri + 64 (+12 per env-map miss); units per launch = rays of that launch
-            b_ray = 64.0 * n_node + 48.0 * n_tri + 64.0 + (12.0 * miss if data.env is not None else 0.0)
-            achieved = sec_rays * b_ray / (sec_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
-                    "algorithmic_gb_per_launch": round(sec_rays / max(sec_launches, 1) * b_ray / 1e9, 2),
-                    "kernel": kernel_name, "bytes_per_ray": round(b_ray, 1), "n_node_per_ray": round(n_node, 3),
-                    "n_tri_per_ray": round(n_tri, 3), "rays_per_launch": round(sec_rays / max(sec_launches, 1), 1),
-                    "avg_launch_ms": round(sec_ms / max(sec_launches, 1), 4), "launches": int(sec_launches),
-                    # consecutive frames run on two streams, so a launch's event window includes the time it shares the GPU
-                    # with (or queues behind) its neighbour; the wall figures divide the timed region by the launches instead
-                    "frames_pipelined": bool(a.pipeline and a.integrator == 0),
-                    "wall_ms_per_launch": round(dt * 1e3 / a.steps, 4),
-                    "achieved_wall": round(sec_rays / max(sec_launches, 1) * b_ray / (dt / a.steps) / 1e9, 1),
-                    "frac_wall": round(sec_rays / max(sec_launches, 1) * b_ray / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                    "working_set_mb": round((nn * 64 + nr * 48) / 1e6, 2),
-                    # issue-side PMC figures of the same command (profiles/r1, scripts/pmc_to_json.py): what binds when HBM does not
-                    "pmc": pmc or None,
-                    "note": ("working set (BVH+triangles) is cache/LDS resident for this workload: algorithmic bytes are served on-chip, so frac is not an HBM utilisation"
-                             if (nn * 64 + nr * 48) < 32e6 else
-                             "working set exceeds the 32 MB of L2; algorithmic bytes above `traffic` are re-reads served by L2 / Infinity Cache")}
-        out = {
-            "metric": "Mrays/s (extension+shadow)", "value": round(total_rays / dt / 1e6, 1), "unit": "Mrays/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.workload}_{W}x{H}_{depth}bounce_1spp_per_gpu_step" + (f"_n{a.grid_n}" if a.workload == "grid" else ""), "width": W, "height": H, "max_depth": depth,
-                       "triangles": data.triangle_count, "bvh": "sbvh" + ("-q4" if sc.bvh_width == 4 else ""), "rng": "node", "integrator": "wave-stacks" if a.integrator == 0 else "level-queues", "parallelism": f"sample-striding x{world}",
-                       "env_map": None if data.env is None else "synthetic 2048x1024"},
-            "spp_per_s": round(a.steps * world / dt, 3), "rays_per_step_per_gpu": round(total_rays / a.steps / world, 1),
-            "shadow_rays": round(total_shadow / a.steps / world, 1), "estimator": ("reference", "light sampling (env map + emissive triangles)", "VNDF specular + cosine diffuse lobes", "VNDF + cosine lobes with light sampling")[a.estimator], "kernel_ms_per_step": round(cnt.kernel_ms / a.steps, 3),
-            "level_ms": [round(prof.ms[k] / a.steps, 3) for k in range(depth)] if a.integrator else None,
-            "level_mrays": [round(prof.rays[k] / a.steps / 1e6, 2) for k in range(depth)] if a.integrator else None,
-            "accumulate_ms": round(prof.accumulate_ms / a.steps, 3),
-            "roofline": roof,
-        }
-        if cpu is not None and world == 1:
-            out["cpu_baseline"] = {"value": round(cpu["mrays"], 2), "unit": "Mrays/s", "cores": min(os.cpu_count() or 1, 16), "kind": "port",
-                                   "sample": f"{cpu['desc']} ({cpu['rays']} rays, {cpu['sec']:.1f} s), same flat BVH"}
+        out = {"metric": "Mrays/s (extension+shadow)", "value": head["value"], "unit": "Mrays/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "estimator": ("reference", "light sampling (env map + emissive triangles)", "VNDF specular + cosine diffuse lobes", "VNDF + cosine lobes with light sampling")[a.estimator]}
+        out.update({k: v for k, v in head.items() if k not in ("value", "unit", "ms_per_step")})
+        if extra:
+            out["workloads"] = extra
         print(json.dumps(out))
     if multi:
         dist.barrier()

@@ -57,12 +57,13 @@ class SceneDesc(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("frames", C.c_uint64), ("kernel_ms", C.c_double), ("launches", C.c_uint64),
-                ("shadow_rays", C.c_uint64)]
+                ("shadow_rays", C.c_uint64), ("kernel_span_ms", C.c_double)]
 
 
 class IssueResult(C.Structure):
     _fields_ = [("ms", C.c_double), ("wave_instructions", C.c_uint64), ("waves", C.c_uint32), ("simds", C.c_uint32),
-                ("median_cycles", C.c_double), ("max_cycles", C.c_double), ("median_realtime_ticks", C.c_double)]
+                ("median_cycles", C.c_double), ("max_cycles", C.c_double), ("median_realtime_ticks", C.c_double),
+                ("clock_ghz", C.c_double)]
 
 
 class LevelProfile(C.Structure):
@@ -144,7 +145,7 @@ lib.mipt_rgbe_decode.argtypes = [_vp, C.c_size_t, _vp, C.POINTER(C.c_uint32), C.
 lib.mipt_rgbe_encode.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp, C.c_size_t]
 lib.mipt_rgbe_encode.restype = C.c_size_t
 lib.mipt_test_math.argtypes = [_vp, C.c_int, _vp, _vp, C.c_uint32, _vp]
-lib.mipt_test_issue.argtypes = [_vp, C.c_uint32, C.c_uint32, C.POINTER(IssueResult)]
+lib.mipt_test_issue.argtypes = [_vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(IssueResult)]
 
 
 class MiptError(RuntimeError):
@@ -437,10 +438,10 @@ class Tracer:
         self._chk(lib.mipt_test_math(self.h, fn, _ptr(a), _ptr(b), len(a), _ptr(out)), "test_math")
         return out
 
-    def test_issue(self, blocks_per_cu, iters):
+    def test_issue(self, blocks_per_cu, iters, packed=0):
         """VALU issue calibration (csrc/microbench.hip): returns an IssueResult."""
         r = IssueResult()
-        self._chk(lib.mipt_test_issue(self.h, blocks_per_cu, iters, C.byref(r)), "test_issue")
+        self._chk(lib.mipt_test_issue(self.h, packed, blocks_per_cu, iters, C.byref(r)), "test_issue")
         return r
 
     def close(self):

@@ -67,7 +67,7 @@ struct mipt_tracer {
     uint32_t flip = 0;               // frames rendered through the pipeline
     int lastSlot = 0;                // ring slot of the most recent frame (mipt_last_sample)
     // counters
-    uint64_t frames = 0, launches = 0; double kernelMs = 0;
+    uint64_t frames = 0, launches = 0; double kernelMs = 0, kernelSpanMs = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     struct LevelEv { hipEvent_t a, b; int level; };   // level -1 = accumulate
     std::vector<LevelEv> levelPending;
@@ -158,11 +158,17 @@ hipEvent_t take_event(mipt_tracer* t) {
 void give_event(mipt_tracer* t, hipEvent_t e) { if (e) t->freeEvents.push_back(e); }
 
 void resolve_events(mipt_tracer* t) {
+    // kernelMs: sum of the launches' own event windows (pipelined launches overlap pairwise, so the windows add up to
+    // more than the time the GPU was busy); kernelSpanMs: per resolved batch, first start to last end -- the time the
+    // integrator kernels actually occupied, whichever stream they ran on
+    float span = 0.f;
     for (auto& p : t->pending) {
         float ms = 0.f;
         if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) t->kernelMs += ms;
-        give_event(t, p.first); give_event(t, p.second);
+        if (hipEventElapsedTime(&ms, t->pending.front().first, p.second) == hipSuccess && ms > span) span = ms;
     }
+    t->kernelSpanMs += span;
+    for (auto& p : t->pending) { give_event(t, p.first); give_event(t, p.second); }
     t->pending.clear();
     for (auto& p : t->levelPending) {
         float ms = 0.f;
@@ -499,7 +505,7 @@ int mipt_get_counters(mipt_tracer* t, mipt_counters* out) {
         HIPCHK(t, hipMemcpy(&rays, t->stats, sizeof rays, hipMemcpyDeviceToHost));
         unsigned long long shadow = 0;
         HIPCHK(t, hipMemcpy(&shadow, t->stats + 38, sizeof shadow, hipMemcpyDeviceToHost));
-        out->rays = rays; out->frames = t->frames; out->kernel_ms = t->kernelMs; out->launches = t->launches; out->shadow_rays = shadow;
+        out->rays = rays; out->frames = t->frames; out->kernel_ms = t->kernelMs; out->launches = t->launches; out->shadow_rays = shadow; out->kernel_span_ms = t->kernelSpanMs;
         return MIPT_OK;
     });
 }
@@ -510,7 +516,7 @@ int mipt_reset_counters(mipt_tracer* t) {
         int rc = mipt_synchronize(t); if (rc) return rc;
         HIPCHK(t, hipMemsetAsync(t->stats, 0, 40 * sizeof(unsigned long long), t->stream));
         HIPCHK(t, hipStreamSynchronize(t->stream));
-        t->frames = 0; t->launches = 0; t->kernelMs = 0;
+        t->frames = 0; t->launches = 0; t->kernelMs = 0; t->kernelSpanMs = 0;
         for (int i = 0; i < 32; i++) { t->levelMs[i] = 0; t->levelLaunches[i] = 0; }
         t->accumulateMs = 0;
         return MIPT_OK;
@@ -1164,7 +1170,7 @@ int mipt_test_math(mipt_tracer* t, int fn, const float* a, const float* b, uint3
 
 // VALU issue calibration (csrc/microbench.hip): `iters` x 64 independent v_fma_f32 per wave on numCU x blocks_per_cu
 // blocks of 256 threads; median per-wave shader-clock cycles and 100 MHz ticks of the loop, HIP-event time of the launch.
-int mipt_test_issue(mipt_tracer* t, uint32_t blocks_per_cu, uint32_t iters, mipt_issue_result* out) {
+int mipt_test_issue(mipt_tracer* t, int packed, uint32_t blocks_per_cu, uint32_t iters, mipt_issue_result* out) {
     return guarded(t, [&]() -> int {
         if (!t || !out || blocks_per_cu < 1 || blocks_per_cu > 8 || iters < 1 || iters > (1u << 24)) return fail(t, MIPT_E_INVALID, "test_issue: blocks_per_cu 1..8, iters 1..2^24");
         if (use(t)) return MIPT_E_HIP;
@@ -1175,17 +1181,19 @@ int mipt_test_issue(mipt_tracer* t, uint32_t blocks_per_cu, uint32_t iters, mipt
         HIPCHK(t, hipMalloc((void**)&sink, 256 * sizeof(float)));
         hipEvent_t a, b;
         HIPCHK(t, hipEventCreate(&a)); HIPCHK(t, hipEventCreate(&b));
-        launch_test_issue(iters, blocks, stamps, sink, t->stream);            // warm-up: code object load, clocks
+        launch_test_issue(packed, iters, blocks, stamps, sink, t->stream);            // warm-up: code object load, clocks
         HIPCHK(t, hipEventRecord(a, t->stream));
-        launch_test_issue(iters, blocks, stamps, sink, t->stream);
+        launch_test_issue(packed, iters, blocks, stamps, sink, t->stream);
         HIPCHK(t, hipEventRecord(b, t->stream));
         HIPCHK(t, hipStreamSynchronize(t->stream));
         float ms = 0.f; HIPCHK(t, hipEventElapsedTime(&ms, a, b));
         std::vector<unsigned long long> h(waves * 2);
         HIPCHK(t, hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         std::vector<unsigned long long> cyc(waves), rt(waves);
-        for (size_t w = 0; w < waves; w++) { cyc[w] = h[2 * w]; rt[w] = h[2 * w + 1]; }
-        std::sort(cyc.begin(), cyc.end()); std::sort(rt.begin(), rt.end());
+        std::vector<double> ghz(waves);
+        for (size_t w = 0; w < waves; w++) { cyc[w] = h[2 * w]; rt[w] = h[2 * w + 1]; ghz[w] = rt[w] ? (double)cyc[w] / ((double)rt[w] * 10.0) : 0.0; }
+        std::sort(cyc.begin(), cyc.end()); std::sort(rt.begin(), rt.end()); std::sort(ghz.begin(), ghz.end());
+        out->clock_ghz = ghz[waves / 2];
         out->ms = ms; out->waves = (uint32_t)waves; out->simds = (uint32_t)t->numCU * 4u;
         out->wave_instructions = (uint64_t)waves * iters * 64ull;
         out->median_cycles = (double)cyc[waves / 2]; out->max_cycles = (double)cyc[waves - 1];

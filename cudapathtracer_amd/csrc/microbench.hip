@@ -26,6 +26,35 @@ namespace mipt {
     asm volatile(MIPT_FMA8_TXT MIPT_FMA8_TXT MIPT_FMA8_TXT MIPT_FMA8_TXT MIPT_FMA8_TXT MIPT_FMA8_TXT MIPT_FMA8_TXT MIPT_FMA8_TXT \
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x_), "v"(y_))
 
+// the packed form: v_pk_fma_f32 does two fp32 FMAs per lane; the chip's 157.3 TFLOP/s fp32 vector peak (spec) is quoted on it
+#define MIPT_PKFMA8_TXT                             \
+    "v_pk_fma_f32 %0, %8, %9, %0\n\t"               \
+    "v_pk_fma_f32 %1, %8, %9, %1\n\t"               \
+    "v_pk_fma_f32 %2, %8, %9, %2\n\t"               \
+    "v_pk_fma_f32 %3, %8, %9, %3\n\t"               \
+    "v_pk_fma_f32 %4, %8, %9, %4\n\t"               \
+    "v_pk_fma_f32 %5, %8, %9, %5\n\t"               \
+    "v_pk_fma_f32 %6, %8, %9, %6\n\t"               \
+    "v_pk_fma_f32 %7, %8, %9, %7\n\t"
+#define MIPT_PKFMA64(x_, y_)                                                                                                      \
+    asm volatile(MIPT_PKFMA8_TXT MIPT_PKFMA8_TXT MIPT_PKFMA8_TXT MIPT_PKFMA8_TXT MIPT_PKFMA8_TXT MIPT_PKFMA8_TXT MIPT_PKFMA8_TXT MIPT_PKFMA8_TXT \
+                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(x_), "v"(y_))
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) k_test_issue_pk(uint32_t iters, float seed, unsigned long long* stamps, float* sink) {
+    float2v p0 = { seed + (float)threadIdx.x, seed }, p1 = p0 + 1.f, p2 = p0 + 2.f, p3 = p0 + 3.f, p4 = p0 + 4.f, p5 = p0 + 5.f, p6 = p0 + 6.f, p7 = p0 + 7.f;
+    const float2v x = { 0.999f + seed, 0.998f + seed }, y = { 1e-3f * seed, 2e-3f * seed };
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t i = 0; i < iters; i++) {
+        MIPT_PKFMA64(x, y);
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63u) == 0u) { stamps[2 * (size_t)wave] = c1 - c0; stamps[2 * (size_t)wave + 1] = r1 - r0; }
+    const float2v s2 = ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
+    if (s2.x + s2.y == 12345.678f) sink[threadIdx.x] = s2.x;
+}
+
 __global__ void __launch_bounds__(256) k_test_issue(uint32_t iters, float seed, unsigned long long* stamps, float* sink) {
     float a0 = seed + (float)threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     const float x = 0.999f + seed, y = 1e-3f * seed;
@@ -40,8 +69,9 @@ __global__ void __launch_bounds__(256) k_test_issue(uint32_t iters, float seed, 
     if (s == 12345.678f) sink[threadIdx.x] = s;      // keeps the chains live; practically never taken
 }
 
-void launch_test_issue(uint32_t iters, int blocks, unsigned long long* stamps, float* sink, hipStream_t s) {
-    hipLaunchKernelGGL(k_test_issue, dim3(blocks), dim3(256), 0, s, iters, 1.0f, stamps, sink);
+void launch_test_issue(int packed, uint32_t iters, int blocks, unsigned long long* stamps, float* sink, hipStream_t s) {
+    if (packed) hipLaunchKernelGGL(k_test_issue_pk, dim3(blocks), dim3(256), 0, s, iters, 1.0f, stamps, sink);
+    else hipLaunchKernelGGL(k_test_issue, dim3(blocks), dim3(256), 0, s, iters, 1.0f, stamps, sink);
 }
 
 }  // namespace mipt

@@ -77,6 +77,9 @@ typedef struct {
     double   kernel_ms;     /* HIP-event time of the integrator kernels */
     uint64_t launches;      /* integrator kernel launches */
     uint64_t shadow_rays;   /* of `rays`: occlusion rays of estimator 1 (0 for the reference's estimator, which has none) */
+    double   kernel_span_ms; /* HIP-event time from the first integrator launch's start to the last one's end, summed over the
+                                batches between synchronisations: pipelined launches overlap pairwise, so this -- not
+                                kernel_ms, the sum of the launches' own windows -- is the time the kernels occupied the GPU */
 } mipt_counters;
 
 /* per recursion level (0 = primary rays): rays traced, HIP-event time of that level's kernel launches, launches.
@@ -257,8 +260,10 @@ int  mipt_test_math(mipt_tracer*, int fn, const float* a, const float* b, uint32
 typedef struct {
     double ms; uint64_t wave_instructions; uint32_t waves, simds;
     double median_cycles, max_cycles, median_realtime_ticks;
+    double clock_ghz;            /* median over waves of cycles / (ticks * 10 ns): the clock the chip held during the loop */
 } mipt_issue_result;
-int  mipt_test_issue(mipt_tracer*, uint32_t blocks_per_cu, uint32_t iters, mipt_issue_result* out);
+/* packed 0: v_fma_f32; 1: v_pk_fma_f32 (two FMAs per lane per instruction) */
+int  mipt_test_issue(mipt_tracer*, int packed, uint32_t blocks_per_cu, uint32_t iters, mipt_issue_result* out);
 
 #ifdef __cplusplus
 }

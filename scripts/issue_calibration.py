@@ -17,19 +17,21 @@ import cudapathtracer_amd as pt
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 t = pt.Tracer(0)
-for wps in (1, 2, 4, 8):
+for packed, wps in [(0, w) for w in (1, 2, 4, 8)] + [(1, w) for w in (1, 2, 4, 8)]:
     best = None
     for rep in range(3):
-        r = t.test_issue(wps, iters)
+        r = t.test_issue(wps, iters, packed)
         if best is None or r.ms < best.ms:
             best = r
     r = best
     per_simd_cycle = wps * iters * 64 / r.median_cycles
-    clock_ghz = r.median_cycles / (r.median_realtime_ticks * 10.0)     # ticks of 10 ns
-    print(json.dumps({"waves_per_simd": wps, "iters": iters, "waves": r.waves, "simds": r.simds,
+    clock_ghz = r.clock_ghz
+    print(json.dumps({"instruction": "v_pk_fma_f32" if packed else "v_fma_f32", "fma_per_lane_per_instruction": 2 if packed else 1,
+                      "fma_lane_ops_per_s_T": round(r.wave_instructions * 64 * (2 if packed else 1) / (r.ms * 1e-3) / 1e12, 2),
+                      "waves_per_simd": wps, "iters": iters, "waves": r.waves, "simds": r.simds,
                       "wave_instructions": r.wave_instructions, "event_ms": round(r.ms, 4),
                       "median_cycles_per_wave": r.median_cycles, "max_cycles_per_wave": r.max_cycles,
                       "cycles_per_wave_instruction_one_wave": round(r.median_cycles / (iters * 64), 3),
                       "wave_instructions_per_simd_cycle": round(per_simd_cycle, 4),
                       "in_kernel_clock_ghz": round(clock_ghz, 3),
-                      "lane_ops_per_s_T": round(r.wave_instructions * 64 / (r.ms * 1e-3) / 1e12, 2)}))
+                      "wave_instructions_per_simd_cycle_by_event_time": round(r.wave_instructions / r.simds / (r.ms * 1e-3 * clock_ghz * 1e9), 4)}))

@@ -3,13 +3,20 @@
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B (MI355X_MICROARCH.md, HBM
 section), so fetched bytes are doubled before they are added to the written bytes.
-valu_busy = 4 * SQ_ACTIVE_INST_VALU / (SIMDs * cycles), cycles = GRBM_GUI_ACTIVE / 8 XCDs, 1024 SIMDs (a wave64 VALU
-instruction occupies its SIMD for four cycles); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU);
+valu_busy = 4 * SQ_ACTIVE_INST_VALU / (SIMDs * cycles), cycles = GRBM_GUI_ACTIVE / 8 XCDs, 1024 SIMDs: an un-packed wave64
+VALU instruction occupies its SIMD for four cycles and SQ_ACTIVE_INST_VALU reads 1.000 per instruction -- both measured with
+mipt::k_test_issue (profiles/r2/issue_calibration.jsonl, issue_calibration_pmc.txt); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU);
 wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES; l2_hit = TCC_HIT / (TCC_HIT + TCC_MISS).
 usage: pmc_to_json.py out.json tag=pass_root [tag=pass_root ...]"""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys, time
 from collections import defaultdict
-out = {}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def source_sha16():      # same hash as bench.py: the figures are attached only to the sources they were measured on
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "kernels.h", "device_math.h", "api.hip", "bvh_builder.cpp"):
+        h.update(open(os.path.join(ROOT, "cudapathtracer_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+out = {"_meta": {"source_sha16": source_sha16(), "collected": "rocprofv3 --pmc passes of `bench.py --workload W --steps 2 --warmup 1`, scripts/pmc_passes.sh, " + time.strftime("%Y-%m-%d")}}
 for tag, root in (a.split("=") for a in sys.argv[2:]):
     tot, n = defaultdict(float), defaultdict(int)
     for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):

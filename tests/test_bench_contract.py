@@ -10,10 +10,27 @@ from conftest import ROOT
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--workload", "default", "--estimator", "1"], ["--integrator", "1", "--depth", "4"]])
+def check_roofline(rf):
+    """the roofline object is a fraction of a bound that can bind: never above 1, whichever bound the workload gets"""
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu", "hbm"):
+        assert k in rf, k
+    assert rf["bound"] in ("valu", "hbm")
+    assert 0.0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-3
+    if rf["bound"] == "hbm":
+        assert rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    else:
+        assert rf["unit"] == "T lane-op/s" and rf["peak"] == 78.65
+    assert 0.0 < rf["valu"]["frac"] <= 1.0 and 0.0 < rf["valu"]["frac_of_unpacked_issue_peak"] <= 1.0
+    assert rf["hbm"]["frac"] > 0.0
+    # PMC traffic is either absent or says where it was measured
+    assert rf["traffic"] is None or "profiles/" in rf["traffic_source"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--workload", "cornell"], ["--workload", "default", "--estimator", "1"], ["--workload", "cornell", "--integrator", "1", "--depth", "4"]])
 def test_bench_prints_one_json_line_with_the_contract_keys(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--width", "320", "--height", "180",
-           "--cpu-seconds", "1"] + extra
+           "--cpu-seconds", "1", "--min-seconds", "0.05"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -26,16 +43,34 @@ def test_bench_prints_one_json_line_with_the_contract_keys(extra):
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
-    rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in rf, k
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    check_roofline(d["roofline"])
+    assert d["roofline"]["bound"] == "valu"             # both scenes are cache resident
+    assert d["repeats"] >= 1 and d["timed_region_s"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "Mrays/s" and cb["value"] > 0 and 1 <= cb["cores"] <= 16 and cb["sample"]
     if "--estimator" in extra:
         assert d["shadow_rays"] > 0
     else:
         assert d["shadow_rays"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_default_command_carries_all_three_workloads():
+    """no --workload: Cornell is the headline, DefaultScene + HDRI and the grid ride along under `workloads`, each with
+    its own roofline fraction in (0, 1] (small frames and a small grid here; the driver runs the full sizes)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--width", "256", "--height", "144",
+           "--cpu-seconds", "1", "--min-seconds", "0.05", "--grid-n", "96"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["workload"].startswith("cornell_") and set(d["workloads"]) == {"default", "grid"}
+    check_roofline(d["roofline"])
+    for name, w in d["workloads"].items():
+        assert w["value"] > 0 and w["ms_per_step"] > 0 and w["config"]["workload"].startswith(name + "_")
+        check_roofline(w["roofline"])
+        assert w["cpu_baseline"]["value"] > 0
 
 
 @pytest.mark.gpu
@@ -46,7 +81,7 @@ def test_bench_multi_gpu_flow_runs_over_rccl_with_one_rank():
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     env = dict(os.environ, BENCH_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--width", "320", "--height", "180",
-           "--cpu-seconds", "1"]
+           "--cpu-seconds", "1", "--min-seconds", "0", "--workload", "cornell"]       # one repeat: the same frames in both runs
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -135,6 +135,22 @@ def test_frame_matches_oracle(tracer, ptlib, oracle, name, w, h, depth, integrat
         tracer.free(acc), tracer.free(ldr)
 
 
+def test_gpu_matches_the_reference_screenshot(tracer, ptlib):
+    """The product itself against the one expected output the reference holds (its Cornell-box README screenshot, as 40 x 24
+    block means; see test_oracle_render.screenshot_agreement): the app's configuration, 800 x 480, maxDepth 4, 256 spp."""
+    from test_oracle_render import screenshot_agreement, check_screenshot_structure
+    sc = ptlib.Scene(tracer, ptlib.builtin_scene(0))
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), 800, 480, 4)
+    acc, _ = dev_buffers(tracer, 800, 480, ldr=False)
+    tracer.render(sc, s, 0, 256, acc)
+    a = tracer.download(acc, (480, 800, 4), np.float32)
+    tracer.free(acc)
+    stats, m, _ = screenshot_agreement(a)
+    for bias, mad, corr in stats:
+        assert abs(bias) < 1.5 and mad < 3.0 and corr > 0.99, stats
+    check_screenshot_structure(m)
+
+
 def test_env_map_lookup(tracer, ptlib, oracle):
     # an open scene: every path ends in an env-map texel (OnMiss, CUDATracerProg.cu:809-844), incl. poles and seam
     env = ptlib.synthetic_sky(128, 64, 7)
@@ -206,9 +222,9 @@ def test_tile_size_does_not_change_the_image(tracer, ptlib):
         assert rays == out[0][1] and rel_err(rgb, out[0][0]).max() < RTOL
 
 
-@pytest.mark.parametrize("name,w,h,depth", [("cornell", 1920, 1080, 8), ("default", 1920, 1080, 12), ("default", 3840, 2160, 4), ("grid", 3840, 2160, 4),
-                                            ("grid10m", 3840, 2160, 4)],
-                         ids=["C2-cornell-1080p-d8", "C3-default-hdri-1080p-d12", "C4-default-hdri-4k-d4", "C5-grid-1Mtri-4k-d4", "C5-grid-10Mtri-4k-d4"])
+@pytest.mark.parametrize("name,w,h,depth", [("cornell", 1920, 1080, 8), ("default", 1920, 1080, 12), ("default", 3840, 2160, 4), ("default", 3840, 2160, 12),
+                                            ("grid", 3840, 2160, 4), ("grid10m", 3840, 2160, 4)],
+                         ids=["C2-cornell-1080p-d8", "C3-default-hdri-1080p-d12", "C4-default-hdri-4k-d4", "C4-default-hdri-4k-d12", "C5-grid-1Mtri-4k-d4", "C5-grid-10Mtri-4k-d4"])
 def test_full_size_properties(tracer, ptlib, oracle, name, w, h, depth):
     """BASELINE configs C2 / C3 / C4 / C5 at their full frame sizes (the default scene under the 2048x1024 synthetic HDRI):
     size-independent properties plus an oracle spot check on three rows."""
