@@ -40,6 +40,7 @@ namespace {
 constexpr float kInf = std::numeric_limits<float>::infinity();
 constexpr int kSpatialBins = 32;
 constexpr int kMaxSpatialDepth = 48;
+constexpr uint32_t kBfsLevelsWide = 0, kBfsLevelsBvh2 = 0;     // breadth-first head of the node array (reorder_nodes)
 
 struct Box {
     float mn[3], mx[3];
@@ -483,6 +484,50 @@ private:
 
 }  // namespace
 
+// Node order.  The builders emit nodes depth-first, so the top of the tree -- which every ray
+// walks -- is scattered over the whole array (a right child sits behind its sibling's entire subtree).  This pass
+// renumbers: the first `headLevels` levels breadth-first at the front of the array (one contiguous block that stays in
+// each XCD's L2), then every subtree hanging below them depth-first as before.  Pure renumbering: boxes, child order
+// within a node and the reference array are untouched, so traversal order and hits do not change.
+void reorder_nodes(std::vector<float>& nodes, int fan, uint32_t headLevels) {
+    const size_t nNodes = nodes.size() / 16;
+    if (nNodes < 2 || headLevels == 0) return;
+    std::vector<uint32_t> order; order.reserve(nNodes);
+    std::vector<uint32_t> level{ 0u }, next, roots;
+    auto kids = [&](uint32_t n, std::vector<uint32_t>& dst) {
+        uint32_t r[4]; memcpy(r, &nodes[(size_t)n * 16 + 12], 16);
+        for (int c = 0; c < fan; c++) if (!(r[c] & kLeafFlag)) dst.push_back(r[c]);
+    };
+    for (uint32_t l = 0; l < headLevels && !level.empty(); l++) {
+        next.clear();
+        for (uint32_t n : level) { order.push_back(n); kids(n, next); }
+        level.swap(next);
+    }
+    roots.swap(level);                       // first level below the head: each subtree stays contiguous, depth-first
+    std::vector<uint32_t> todo, tmp;
+    for (uint32_t r : roots) {
+        todo.assign(1, r);
+        while (!todo.empty()) {
+            const uint32_t n = todo.back(); todo.pop_back();
+            order.push_back(n);
+            tmp.clear(); kids(n, tmp);
+            for (size_t k = tmp.size(); k-- > 0;) todo.push_back(tmp[k]);
+        }
+    }
+    if (order.size() != nNodes) return;      // not a tree rooted at 0 (cannot happen for builder output): leave as is
+    std::vector<uint32_t> newIndex(nNodes);
+    for (size_t k = 0; k < nNodes; k++) newIndex[order[k]] = (uint32_t)k;
+    std::vector<float> out(nodes.size());
+    for (size_t k = 0; k < nNodes; k++) {
+        float* D = &out[k * 16];
+        memcpy(D, &nodes[(size_t)order[k] * 16], 64);
+        uint32_t r[4]; memcpy(r, D + 12, 16);
+        for (int c = 0; c < fan; c++) if (!(r[c] & kLeafFlag)) r[c] = newIndex[r[c]];
+        memcpy(D + 12, r, 16);
+    }
+    nodes.swap(out);
+}
+
 std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOut& out) {
     // worker threads: $MIPT_BUILD_THREADS, else the hardware's, at most 16 (a GPU box's CPU share)
     int threads = (int)std::thread::hardware_concurrency();
@@ -510,6 +555,11 @@ std::string build_bvh(const std::vector<TriPos>& tris, const BvhParams& p, BvhOu
         out.nodes.swap(wide);
         out.width = 4; out.maxDepth = c.maxDepth; out.stackNeed = need;
     }
+    // breadth-first head: 8 levels of 4-wide nodes (<= 21 845 nodes, 1.4 MB) or 14 levels of BVH2; $MIPT_BFS_LEVELS overrides
+    // (0 = the builders' depth-first order); measured in profiles/r2/exp_node_order.log
+    uint32_t head = out.width == 4 ? kBfsLevelsWide : kBfsLevelsBvh2;
+    if (const char* e = std::getenv("MIPT_BFS_LEVELS")) head = (uint32_t)std::atoi(e);
+    reorder_nodes(out.nodes, out.width == 4 ? 4 : 2, head);
     return "";
 }
 
