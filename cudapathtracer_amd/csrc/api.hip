@@ -335,13 +335,26 @@ int gather_geometry(mipt_tracer* t, const mipt_scene_desc* d, std::vector<TriPos
 }
 
 // reference records (base vertex, two edges, triangle id, mesh id) in leaf order, and the 12-float material records
-void fill_refs(const std::vector<uint32_t>& refTri, const std::vector<TriPos>& tris, const std::vector<uint32_t>& triMesh, std::vector<float>& refs) {
+// a mesh whose hits can add emission (CUDATracerProg.cu:528 adds emissiveColor * emissiveStrength at every hit)
+bool mesh_emits(const mipt_material& m) {
+    return m.emissiveStrength != 0.f && (m.emissiveColor[0] != 0.f || m.emissiveColor[1] != 0.f || m.emissiveColor[2] != 0.f);
+}
+uint32_t count_emissive_meshes(const mipt_scene_desc* d) {
+    uint32_t n = 0;
+    for (uint32_t m = 0; m < d->meshCnt; m++) if (mesh_emits(d->meshes[m].material)) n++;
+    return n;
+}
+// The last word of a reference record (e2.w) is a flag word: bit 1 = the triangle's mesh emits.  The integrator reads it
+// with the triangle it has fetched anyway, so a ray that ends on a non-emitting surface at the last level needs no
+// shading-record / material fetch to know that it adds nothing.
+void fill_refs(const mipt_scene_desc* d, const std::vector<uint32_t>& refTri, const std::vector<TriPos>& tris, const std::vector<uint32_t>& triMesh, std::vector<float>& refs) {
     refs.resize(refTri.size() * 12);
     for (size_t r = 0; r < refTri.size(); r++) {
         uint32_t g = refTri[r]; const TriPos& tp = tris[g];
         float* R = &refs[r * 12];
         for (int a = 0; a < 3; a++) { R[a] = tp.v[0][a]; R[4 + a] = tp.v[1][a] - tp.v[0][a]; R[8 + a] = tp.v[2][a] - tp.v[0][a]; }
-        memcpy(&R[3], &g, 4); memcpy(&R[7], &triMesh[g], 4); R[11] = 0.f;
+        const uint32_t flags = mesh_emits(d->meshes[triMesh[g]].material) ? 2u : 0u;
+        memcpy(&R[3], &g, 4); memcpy(&R[7], &triMesh[g], 4); memcpy(&R[11], &flags, 4);
     }
 }
 void fill_materials(const mipt_scene_desc* d, std::vector<float>& mats) {
@@ -476,7 +489,7 @@ int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
         else if (k == "count_pixel_rays") t->countPixelRays = v ? 1 : 0;
         else if (k == "refill_lanes") { if (v < 1 || v > 64) return fail(t, MIPT_E_INVALID, "refill_lanes out of range"); t->refillLanes = v; }
         else if (k == "min_descend_lanes") { if (v < 0 || v > 64) return fail(t, MIPT_E_INVALID, "min_descend_lanes out of range"); t->minDescend = v; }
-        else if (k == "xcd_bands") { if (v < -1 || v > 1) return fail(t, MIPT_E_INVALID, "xcd_bands must be -1 (auto), 0 or 1"); t->xcdBands = v; }
+    else if (k == "xcd_bands") { if (v < -1 || v > 1) return fail(t, MIPT_E_INVALID, "xcd_bands must be -1 (auto), 0 or 1"); t->xcdBands = v; }
         else if (k == "pipeline_frames") t->pipelineFrames = v ? 1 : 0;
         else if (k == "keep_sample") t->keepSample = v ? 1 : 0;
         else if (k == "estimator") { if (v < 0 || v > 3) return fail(t, MIPT_E_INVALID, "estimator must be 0 (reference), 1 (light sampling), 2 (VNDF + cosine lobes) or 3 (both)"); t->estimator = v; }
@@ -574,7 +587,7 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
         s->t = t; s->nMeshes = d->meshCnt; s->nTris = (uint32_t)tris.size(); s->bvhFromCache = cached; s->bvhWidth = bo.width;
         s->hNodes = std::move(bo.nodes);
         s->hRefTri = bo.refTri;
-        fill_refs(s->hRefTri, tris, triMesh, s->hRefs);
+        fill_refs(d, s->hRefTri, tris, triMesh, s->hRefs);
         std::vector<float> mats; fill_materials(d, mats);
         if (d->envMap && d->envW && d->envH) build_env_cdf(d->envMap, d->envW, d->envH, s->hEnvCdf);
         const float emitScale = build_emitters(d, tris, triMesh, s->hEmitTri, s->hEmitCdf);
@@ -607,6 +620,7 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
         s->dev.nNodes = (uint32_t)(s->hNodes.size() / 16); s->dev.nRefs = (uint32_t)bo.refTri.size();
         s->dev.wide = bo.width == 4 ? 1u : 0u;
         s->dev.stackNeed = bo.stackNeed;
+        s->dev.emissiveMeshes = count_emissive_meshes(d);
         if (t) hipDeviceSynchronize();
         *out = s;
         return MIPT_OK;
@@ -644,7 +658,7 @@ int mipt_scene_refit(mipt_scene* s, const mipt_scene_desc* d) {
         std::string err = refit_bvh(bo, tris);
         if (!err.empty()) return fail(t, MIPT_E_LIMIT, "BVH refit: " + err);
         std::vector<float> refs, mats, emitTri, emitCdf;
-        fill_refs(s->hRefTri, tris, triMesh, refs);
+        fill_refs(d, s->hRefTri, tris, triMesh, refs);
         fill_materials(d, mats);
         const float emitScale = build_emitters(d, tris, triMesh, emitTri, emitCdf);
         if (t) {
@@ -670,6 +684,7 @@ int mipt_scene_refit(mipt_scene* s, const mipt_scene_desc* d) {
             s->dev.emitTri = (const float*)s->dEmitTri; s->dev.emitCdf = (const float*)s->dEmitCdf;
             s->dev.nEmit = (uint32_t)nEmit; s->dev.emitScale = emitScale;
         }
+        s->dev.emissiveMeshes = count_emissive_meshes(d);
         // the analytic sky is a launch parameter, not a buffer: taken from the desc as well (the env map stays)
         memcpy(s->dev.skyColor, d->sky.color, 12); memcpy(s->dev.skyDir, d->sky.dir, 12); s->dev.skyIntensity = d->sky.intensity;
         s->hNodes.swap(bo.nodes); s->hRefs.swap(refs); s->hEmitTri.swap(emitTri); s->hEmitCdf.swap(emitCdf);
@@ -873,7 +888,7 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
                 // min_descend_lanes auto: 8 for an LDS-resident scene, 24 otherwise (measured optima, profiles/r1/exp_min_descend.log)
                 const bool ldsScene = wavestack_scene_in_lds(sc->dev);
                 SA.minDescend = (uint32_t)(t->minDescend > 0 ? t->minDescend : (ldsScene ? 8 : 24));
-                SA.pixCounter = counts; SA.nee = (uint32_t)t->estimator;
+            SA.pixCounter = counts; SA.nee = (uint32_t)t->estimator;
                 // xcd_bands auto: on when nodes + references exceed one XCD's 4 MiB L2 or the frame has 4 Mi pixels or more.
                 // Eight counters also spread the claims (one word sustains ~90 atomics/us, MI355X_MICROARCH.md; frames of cheap
                 // pixels come close to that), which fits the gain growing as the pixels get cheaper: 4K grids

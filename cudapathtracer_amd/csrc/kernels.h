@@ -8,7 +8,7 @@ namespace mipt {
 // Scene as the kernels see it.  Everything is flat, 16-byte aligned float4 streams in HBM:
 //   nodes : 4 x float4 per BVH2 node (both children's boxes + two child refs)     64 B
 //           or, when `wide` is set, per quantised 4-wide node (bvh_builder.h)     64 B
-//   refs  : 3 x float4 per triangle reference (v0|triId, e1|meshId, e2|0)          48 B
+//   refs  : 3 x float4 per triangle reference (v0|triId, e1|meshId, e2|flags)      48 B   flags bit 1: the mesh emits
 //   shade : 3 x float4 per triangle (unit vertex normals n0|meshId, n1, n2)        48 B, touched only for the winning hit
 //   mats  : 3 x float4 per mesh (color|roughness, metallic opacity n emissiveStrength, emissiveColor|0)
 struct SceneDev {
@@ -27,6 +27,8 @@ struct SceneDev {
     const float* emitTri;     // estimator 1: emissive triangles, 15 floats each [v0 e1 e2 unit-normal Le]; nullptr if none
     const float* emitCdf;     // area CDF, nEmit + 1 entries
     uint32_t nEmit; float emitScale;   // total emissive area / (2 pi 0.98)
+    uint32_t emissiveMeshes;  // meshes whose hits can add emission (strength != 0 and a non-black colour); 0: a hit at the last
+                              // level adds nothing, whichever triangle it is, so those rays only need to know hit-or-miss
 };
 
 // Per-frame constants computed once on the host (CUDATracerProg.cu:369-397 computes them per thread).

@@ -155,16 +155,21 @@ MIPT_DEV int wide_visit(const RayPre& r, float4 n0, float4 n1, float4 n2, float4
     const uint32_t hx = __float_as_uint(n1.w), hy = __float_as_uint(n2.x), hz = __float_as_uint(n2.y);
     float t[4]; uint32_t ref[4] = { __float_as_uint(n3.x), __float_as_uint(n3.y), __float_as_uint(n3.z), __float_as_uint(n3.w) };
     int n = 0;
+    // Entry / exit planes picked by the ray's octant: one select per axis word serves all four children, and a child
+    // costs max3 / min3 instead of three min + three max.  Same values as min(lo, hi) / max(lo, hi): q_lo <= q_hi and the
+    // FMA is monotonic in q, so for idir > 0 the low plane is the entry plane and for idir < 0 the high one.
+    const bool ngx = r.idir.x < 0.f, ngy = r.idir.y < 0.f, ngz = r.idir.z < 0.f;
+    const uint32_t ex = ngx ? hx : lx, fx = ngx ? lx : hx;
+    const uint32_t ey = ngy ? hy : ly, fy = ngy ? ly : hy;
+    const uint32_t ez = ngz ? hz : lz, fz = ngz ? lz : hz;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int sh = 8 * i;
-        float tlx = ffma((float)((lx >> sh) & 0xFFu), ix, ox), thx = ffma((float)((hx >> sh) & 0xFFu), ix, ox);
-        float tly = ffma((float)((ly >> sh) & 0xFFu), iy, oy), thy = ffma((float)((hy >> sh) & 0xFFu), iy, oy);
-        float tlz = ffma((float)((lz >> sh) & 0xFFu), iz, oz), thz = ffma((float)((hz >> sh) & 0xFFu), iz, oz);
-        float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tlx, thx), __builtin_fminf(tly, thy)),
-                                     __builtin_fmaxf(__builtin_fminf(tlz, thz), 0.0f));
-        float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tlx, thx), __builtin_fmaxf(tly, thy)),
-                                     __builtin_fminf(__builtin_fmaxf(tlz, thz), hitT));
+        const float tex = ffma((float)((ex >> sh) & 0xFFu), ix, ox), tfx = ffma((float)((fx >> sh) & 0xFFu), ix, ox);
+        const float tey = ffma((float)((ey >> sh) & 0xFFu), iy, oy), tfy = ffma((float)((fy >> sh) & 0xFFu), iy, oy);
+        const float tez = ffma((float)((ez >> sh) & 0xFFu), iz, oz), tfz = ffma((float)((fz >> sh) & 0xFFu), iz, oz);
+        const float tmin = __builtin_fmaxf(__builtin_fmaxf(tex, tey), __builtin_fmaxf(tez, 0.0f));
+        const float tmax = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, hitT));
         const bool hit = tmin <= tmax && ref[i] != kEmptyRef;
         t[i] = hit ? tmin : __builtin_inff();
         n += hit ? 1 : 0;
@@ -509,6 +514,12 @@ MIPT_DEV uint32_t band_pixel(const Band& b, uint32_t local) { return ((local / b
 template <bool LDS_SCENE> struct SqCap { static constexpr int value = LDS_SCENE ? 96 : 112; };
 constexpr int kSqWords = 16;         // dwords per entry, SoA by dword: conflict-free LDS access
 
+// wave-stack records: plain cached accesses.  The stack is LIFO, so what was pushed last is popped next and L2 is exactly
+// where it should sit; non-temporal stores / loads were measured 13 % (Cornell) and 9 % (Default) slower, grid unchanged
+// (profiles/r2/exp_rejected_variants.log)
+MIPT_DEV void stack_store(float4* p, float4 v) { *p = v; }
+MIPT_DEV float4 stack_load(const float4* p) { return *p; }
+
 template <bool LDS_SCENE>
 MIPT_DEV void load_node(const float4* lds, const float4* glb, uint32_t cur, float4& n0, float4& n1, float4& n2, float4& n3) {
     if constexpr (LDS_SCENE) { const float4* N = lds + (size_t)cur * 4; n0 = N[0]; n1 = N[1]; n2 = N[2]; n3 = N[3]; }
@@ -625,6 +636,13 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     int tsp = 0;
     uint32_t traced = 0, shadowTraced = 0;
     MIPT_PROF(unsigned long long pf[12] = {};)
+    // Work that cannot change the image is not done (the rays are still traced and counted):
+    //  * a ray that ends (miss, or hit at the last level) without anything to add -- black analytic sky, non-emitting
+    //    surface, flagged-off term of the light-sampling estimators -- is retired on the spot instead of being parked in
+    //    the shade queue and run through a terminal batch (in a full binary tree half of all rays are at the last level);
+    //  * in a scene without emitting meshes a last-level ray only needs hit-or-miss: it stops at its first triangle hit.
+    // (the "emits" flag of the closest triangle so far rides in the sign bit of h.u -- u >= 0 -- so it costs no register)
+    const bool skyBlack = A.S.env == nullptr && A.S.skyIntensity == 0.f;
 
     while (true) {
         const unsigned long long actMask = __ballot(active);
@@ -697,25 +715,25 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     const uint32_t w = sp + 2u * lane;
                     uint32_t flags2 = 0;
                     if (NEE && opaque) flags2 = (A.S.envCdf ? kNoEnvBit : 0u) | (A.S.nEmit ? kNoEmitBit : 0u);
-                    qa[w] = make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x);
-                    qb[w] = make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y);
-                    qc[w] = make_float4(b.f1.z, __uint_as_float(spix), __uint_as_float(snode * 2u), __uint_as_float(ss0));
-                    qa[w + 1] = make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x);
-                    qb[w + 1] = make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y);
-                    qc[w + 1] = make_float4(b.f2.z, __uint_as_float(spix | flags2), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0));
+                    stack_store(&qa[w], make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x));
+                    stack_store(&qb[w], make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y));
+                    stack_store(&qc[w], make_float4(b.f1.z, __uint_as_float(spix), __uint_as_float(snode * 2u), __uint_as_float(ss0)));
+                    stack_store(&qa[w + 1], make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x));
+                    stack_store(&qb[w + 1], make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y));
+                    stack_store(&qc[w + 1], make_float4(b.f2.z, __uint_as_float(spix | flags2), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0)));
                 }
                 // occlusion rays: the record's node word carries tmax (+inf towards the environment)
                 if (NEE && wantEnv) {
                     const uint32_t w = sp + 2u * n + (uint32_t)__popcll(sm & below);
-                    qa[w] = make_float4(b.o2.x, b.o2.y, b.o2.z, sdir.x);
-                    qb[w] = make_float4(sdir.y, sdir.z, scon.x, scon.y);
-                    qc[w] = make_float4(scon.z, __uint_as_float(spix | kShadowBit), __builtin_inff(), __uint_as_float(ss0));
+                    stack_store(&qa[w], make_float4(b.o2.x, b.o2.y, b.o2.z, sdir.x));
+                    stack_store(&qb[w], make_float4(sdir.y, sdir.z, scon.x, scon.y));
+                    stack_store(&qc[w], make_float4(scon.z, __uint_as_float(spix | kShadowBit), __builtin_inff(), __uint_as_float(ss0)));
                 }
                 if (NEE && wantEmit) {
                     const uint32_t w = sp + 2u * n + nEnvRays + (uint32_t)__popcll(em & below);
-                    qa[w] = make_float4(b.o2.x, b.o2.y, b.o2.z, edir.x);
-                    qb[w] = make_float4(edir.y, edir.z, econ.x, econ.y);
-                    qc[w] = make_float4(econ.z, __uint_as_float(spix | kShadowBit), etmax, __uint_as_float(ss0));
+                    stack_store(&qa[w], make_float4(b.o2.x, b.o2.y, b.o2.z, edir.x));
+                    stack_store(&qb[w], make_float4(edir.y, edir.z, econ.x, econ.y));
+                    stack_store(&qc[w], make_float4(econ.z, __uint_as_float(spix | kShadowBit), etmax, __uint_as_float(ss0)));
                 }
                 sp += total;
             }
@@ -785,7 +803,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                         if (A.alphaOne) A.sample[(size_t)pix * 4 + 3] = 1.f;
                     } else {
                         const uint32_t e = sp + (rank - got);
-                        float4 ra = qa[e], rb = qb[e], rc = qc[e];
+                        float4 ra = stack_load(qa + e), rb = stack_load(qb + e), rc = stack_load(qc + e);
                         o = xyz(ra); d = mk3(ra.w, rb.x, rb.y); beta = mk3(rb.z, rb.w, rc.x);
                         pix = __float_as_uint(rc.y); node = __float_as_uint(rc.z); s0 = __float_as_uint(rc.w);
                     }
@@ -797,6 +815,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     active = true;
                     traced++;
                     if constexpr (NEE) if (pix & kShadowBit) { shadowTraced++; h.t = __uint_as_float(node); }    // stops short of the emitter
+
                     if (A.pixelRays) atomicAdd(A.pixelRays + (pix & (NEE ? kPixMask : 0xFFFFFFFFu)), 1u);
                 }
             }
@@ -855,6 +874,9 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 }
             }
         }
+        // (a bounded-tail loop over triangles or over whole leaves -- lanes that finish a leaf pop and go on testing while
+        // their neighbours work through longer leaves -- raised the leaf phase's lane utilisation but cost 2-4 % overall:
+        // profiles/r2/exp_rejected_variants.log)
         if (active) {
             if ((cur & kLeaf) && cur != kTerm) {
                 uint32_t cnt = (cur >> 27) & 0xFu, first = cur & 0x07FFFFFFu;
@@ -864,10 +886,16 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     load_ref<LDS_SCENE>(ldsRefs, A.S.refs, i, a, b, c);
                     float tt, uu, vv; bool ff;
                     int id = (int)__float_as_uint(a.w);
-                    if (mt_test(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) { h.t = tt; h.u = uu; h.v = vv; h.front = ff; h.ref = (int)i; h.tri = id; }
+                    if (mt_test(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) {
+                        h.t = tt; h.u = uu; h.v = vv; h.front = ff; h.ref = (int)i; h.tri = id;
+                        h.u = __uint_as_float(__float_as_uint(uu) | (__float_as_uint(c.w) << 30));     // flags bit 1 -> sign bit
+                    }
                 }
                 if constexpr (LDS_SCENE) MIPT_STACK_POP_L(lstk, tsp, cur); else MIPT_STACK_POP(lstk, deep, tsp, cur);
                 if constexpr (NEE) if ((pix & kShadowBit) && h.tri >= 0) cur = kTerm;      // occlusion ray: any hit ends it
+                // no emitting mesh in the scene: a last-level ray adds nothing if it hits anything, so its first hit ends it
+                // (its level is recomputed from the node id: cheaper than a register held through the traversal)
+                if (A.S.emissiveMeshes == 0u) { if (h.tri >= 0 && (32u - (uint32_t)__clz((int)node)) >= A.F.maxDepth) cur = kTerm; }
             }
         }
         MIPT_PROF(pf[0]++; pf[1] += (uint32_t)__popcll(__ballot(active)); pf[2] += wave_max_u32(myNodes); pf[3] += wave_sum_u32(myNodes);
@@ -875,11 +903,18 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
         bool fin = active && cur == kTerm;
         unsigned long long fm = __ballot(fin);
         if (fm) {
-            // no room: stay terminated-but-unparked until the queue has been drained
-            fin = fin && nF + nT + (uint32_t)__popcll(fm & below) < (uint32_t)kSqCap;
             const uint32_t level = 31u - (uint32_t)__clz((int)node);             // root = 1 -> level 0
             const bool term = h.tri < 0 || level + 1 >= A.F.maxDepth              // children would have ttl 0 (CUDATracerProg.cu:433)
                               || (NEE && (pix & kShadowBit));
+            if (fin && term) {
+                const bool shadow = NEE && (pix & kShadowBit);
+                const bool dead = h.tri < 0 ? (!shadow && (skyBlack || (NEE && (pix & kNoEnvBit))))
+                                            : (shadow || !(__float_as_uint(h.u) >> 31) || (NEE && (pix & kNoEmitBit)));
+                if (dead) { active = false; fin = false; }
+            }
+            fm = __ballot(fin);
+            // no room: stay terminated-but-unparked until the queue has been drained
+            fin = fin && nF + nT + (uint32_t)__popcll(fm & below) < (uint32_t)kSqCap;
             const unsigned long long mF = __ballot(fin && !term), mT = __ballot(fin && term);
             if (fin) {
                 const uint32_t e = term ? (uint32_t)kSqCap - 1u - (nT + (uint32_t)__popcll(mT & below)) : nF + (uint32_t)__popcll(mF & below);
@@ -888,7 +923,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 sq[3 * kSqCap + e] = d.x; sq[4 * kSqCap + e] = d.y; sq[5 * kSqCap + e] = d.z;
                 sq[6 * kSqCap + e] = beta.x; sq[7 * kSqCap + e] = beta.y; sq[8 * kSqCap + e] = beta.z;
                 sqi[9 * kSqCap + e] = pix; sqi[10 * kSqCap + e] = node; sqi[11 * kSqCap + e] = s0;
-                sq[12 * kSqCap + e] = h.u; sq[13 * kSqCap + e] = h.v;
+                sq[12 * kSqCap + e] = __builtin_fabsf(h.u); sq[13 * kSqCap + e] = h.v;
                 sqi[14 * kSqCap + e] = h.tri < 0 ? 0xFFFFFFFFu : ((uint32_t)h.tri | (h.front ? 0x80000000u : 0u));
                 active = false;
             }

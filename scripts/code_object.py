@@ -30,9 +30,9 @@ def main():
         local = os.path.join(tmp, os.path.basename(lib))
         shutil.copy(lib, local)
         subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, capture_output=True, cwd=tmp)
-        co = [f for f in os.listdir(tmp) if "amdgcn" in f]
+        co = sorted(f for f in os.listdir(tmp) if "amdgcn" in f)          # one code object per .hip translation unit
         assert co, "no gfx950 code object found"
-        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, co[0])], capture_output=True, text=True, check=True).stdout
+        notes = "".join(subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, f)], capture_output=True, text=True, check=True).stdout for f in co)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     kernels, cur = [], None

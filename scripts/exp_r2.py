@@ -5,7 +5,7 @@
 
 A variant is a name, optionally a library (path relative to cudapathtracer_amd/, loaded through MIPT_LIB; built with
 `make -C cudapathtracer_amd/csrc variant NAME=x EXTRA=-DMIPT_EXP_...`), optionally environment settings and bench
-options (OPT:key=value -> bench.py --option key=value).  Every run is its own process with a time limit.
+options (opt.key=value -> bench.py --option key=value).  Every run is its own process with a time limit.
 """
 import json
 import os
@@ -31,8 +31,8 @@ for spec in args:
     for p in parts[1:]:
         if p.endswith(".so"):
             env["MIPT_LIB"] = os.path.join(ROOT, "cudapathtracer_amd", p)
-        elif p.startswith("OPT"):
-            opts += ["--option", p[3:].lstrip(":")]
+        elif p.startswith("opt."):
+            opts += ["--option", p[4:]]
         elif p.startswith("ARG"):
             extra += p[3:].split("=")
         else:
