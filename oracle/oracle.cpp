@@ -413,6 +413,7 @@ struct orc_scene {
     std::vector<float> fnodes, ftris;
     uint32_t fwidth = 2;             // 2: BVH2 nodes, 4: quantised 4-wide nodes
     int estimator = 0;
+    bool anyhitLast = false, anyEmits = false;     // see LaunchRayRecur
     std::vector<float> envCdf;       // rowCdf[H+1], then H x colCdf[W+1]
     float neeScale = 0.f;            // pi / (0.98 * W * H): p_cap * texel solid angle / sin(theta)
     // emissive triangles (estimator 1): 15 floats each [v0 e1 e2 n Le], area CDF [n+1], total area / (2 pi 0.98)
@@ -519,7 +520,7 @@ Hit isect_brute(const orc_scene& s, v3 o, v3 d, Counters* c) {
 //     inner = node index.  Order: nearer child first, farther pushed; leaves tested when they become current; hitT
 //     shrinks as hits are found and culls later box tests (tnear <= hitT).  No re-test at pop. ---
 inline int32_t fbits(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
-Hit isect_flat(const orc_scene& s, v3 o, v3 d, Counters* c) {
+Hit isect_flat(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false) {
     RayPre r = ray_pre(o, d);
     Hit best; best.t = INFINITY; best.tri = -1; best.u = best.v = 0; best.front = false;
     if (s.fnodes.empty()) return best;
@@ -535,6 +536,7 @@ Hit isect_flat(const orc_scene& s, v3 o, v3 d, Counters* c) {
                     best.t = tt; best.u = uu; best.v = vv; best.front = ff; best.tri = fbits(T[3]);
                 }
             }
+            if (anyhit && best.tri >= 0) return best;          // the product's last-level shortcut: the leaf is finished, then the ray ends
         } else {
             const float* N = &s.fnodes[(size_t)cur * 16]; c->nodes++;
             float t0, t1;
@@ -562,7 +564,7 @@ Hit isect_flat(const orc_scene& s, v3 o, v3 d, Counters* c) {
 //     (kernels.hip wide_visit): t = q * (idir * 2^(e-127)) + (origin - o) * idir.  Hit children are visited nearest
 //     first (5-exchange sorting network, swap iff tb < ta), the others pushed farthest first. ---
 inline float ubits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c) {
+Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false) {
     RayPre r = ray_pre(o, d);
     Hit best; best.t = INFINITY; best.tri = -1; best.u = best.v = 0; best.front = false;
     if (s.fnodes.empty()) return best;
@@ -578,6 +580,7 @@ Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c) {
                     best.t = tt; best.u = uu; best.v = vv; best.front = ff; best.tri = fbits(T[3]);
                 }
             }
+            if (anyhit && best.tri >= 0) return best;          // the product's last-level shortcut: the leaf is finished, then the ray ends
         } else {
             const float* N = &s.fnodes[(size_t)cur * 16]; c->nodes++;
             const uint32_t eb = (uint32_t)fbits(N[3]);
@@ -615,9 +618,9 @@ Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c) {
     }
     return best;
 }
-inline Hit isect(const orc_scene& s, int mode, v3 o, v3 d, Counters* c) {
+inline Hit isect(const orc_scene& s, int mode, v3 o, v3 d, Counters* c, bool anyhit = false) {
     c->rays++;
-    Hit h = mode == ORC_ISECT_REF ? isect_ref(s, o, d, c) : mode == ORC_ISECT_FLAT ? (s.fwidth == 4 ? isect_flat4(s, o, d, c) : isect_flat(s, o, d, c)) : isect_brute(s, o, d, c);
+    Hit h = mode == ORC_ISECT_REF ? isect_ref(s, o, d, c) : mode == ORC_ISECT_FLAT ? (s.fwidth == 4 ? isect_flat4(s, o, d, c, anyhit) : isect_flat(s, o, d, c, anyhit)) : isect_brute(s, o, d, c);
     if (h.tri >= 0) c->hits++;
     return h;
 }
@@ -831,8 +834,13 @@ v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noE
     v3 color = mk(0, 0, 0);
     if (ttl <= 0) return color;
     k.pixel_rays++;
-    Hit h = isect(*k.s, k.isect, o, d, k.c);
+    // Work-counting option (orc_scene_set_anyhit_last_level; off by default, FLAT intersector only): the product ends a
+    // last-level ray at its first hit when no mesh of the scene emits -- such a ray adds nothing if it hits anything.  The
+    // image is the same either way; only node visits / triangle tests (the roofline's algorithmic counts) change.
+    const bool anyhit = k.s->anyhitLast && ttl == 1 && !k.s->anyEmits;
+    Hit h = isect(*k.s, k.isect, o, d, k.c, anyhit);
     if (h.tri < 0) return noEnv ? color : OnMiss(k, d);
+    if (anyhit) return color;
     const OMesh& m = k.s->meshes[k.s->triMesh[h.tri]];
     uint32_t lt = k.s->triLocal[h.tri];
     const orc_material& mat = m.mat;
@@ -1031,6 +1039,13 @@ int orc_scene_set_flat_bvh(orc_scene* s, const float* nodes, uint32_t n_nodes, c
     return 0;
 }
 int orc_scene_set_estimator(orc_scene* s, int e) { if (e < 0 || e > 3) return 1; s->estimator = e; return 0; }
+int orc_scene_set_anyhit_last_level(orc_scene* s, int on) {
+    s->anyhitLast = on != 0;
+    s->anyEmits = false;
+    for (const OMesh& m : s->meshes)
+        if (m.mat.emissiveStrength != 0.f && (m.mat.emissiveColor[0] != 0.f || m.mat.emissiveColor[1] != 0.f || m.mat.emissiveColor[2] != 0.f)) s->anyEmits = true;
+    return 0;
+}
 uint64_t orc_scene_get_env_cdf(const orc_scene* s, float* out, uint64_t cap) {
     if (out && cap >= s->envCdf.size()) memcpy(out, s->envCdf.data(), s->envCdf.size() * sizeof(float));
     return s->envCdf.size();

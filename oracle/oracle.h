@@ -120,6 +120,9 @@ int orc_trace_rays(const orc_scene*, int isect, const float* origins, const floa
  *       the emissive triangles (three more draws) and connected with an occlusion ray.  Same expectation as estimator 0.
  * Acts on whichever of env map / emissive triangles the scene has; needs RNG_NODE; ignored otherwise. */
 int orc_scene_set_estimator(orc_scene*, int estimator);
+/* work-counting option for the FLAT intersector: last-level rays stop at their first hit when no mesh emits (what the product
+ * does; same image, fewer node visits / triangle tests).  Off by default: every other mode is the reference's closest hit. */
+int orc_scene_set_anyhit_last_level(orc_scene*, int on);
 /* the sampling tables of estimator 1: rowCdf[H+1] then H rows of colCdf[W+1]; returns the float count (0 = no env map) */
 uint64_t orc_scene_get_env_cdf(const orc_scene*, float* out, uint64_t cap);
 

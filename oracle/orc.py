@@ -84,6 +84,7 @@ lib.orc_scene_set_flat_bvh.argtypes = [_vp, _vp, C.c_uint32, _vp, C.c_uint32]
 lib.orc_check_flat_bvh.argtypes = [_vp, C.c_char_p, C.c_uint32]
 lib.orc_scene_set_flat_width.argtypes = [_vp, C.c_uint32]
 lib.orc_scene_set_estimator.argtypes = [_vp, C.c_int]
+lib.orc_scene_set_anyhit_last_level.argtypes = [_vp, C.c_int]
 lib.orc_scene_get_env_cdf.argtypes = [_vp, _vp, C.c_uint64]
 lib.orc_scene_get_env_cdf.restype = C.c_uint64
 lib.orc_scene_get_emitters.argtypes = [_vp, _vp, _vp, C.c_uint64]
@@ -174,6 +175,10 @@ class Scene:
         lib.orc_scene_set_flat_bvh(self.h, _ptr(nodes), len(nodes), _ptr(refs), len(refs))
         if lib.orc_scene_set_flat_width(self.h, width) != 0:
             raise ValueError("width must be 2 or 4")
+
+    def set_anyhit_last_level(self, on=True):
+        """FLAT intersector: last-level rays end at their first hit when no mesh emits (the product's shortcut); counts only."""
+        lib.orc_scene_set_anyhit_last_level(self.h, 1 if on else 0)
 
     def set_estimator(self, estimator):
         """0 = the reference's estimator, 1 = light sampling, 2 = VNDF + cosine lobes, 3 = both (specification: include/mipt.h)."""

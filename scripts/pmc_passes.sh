@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 run() {   # name, counters...
   local name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --min-seconds 0 "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1
   local rc=$?
   echo "pass $name rc=$rc"
   return $rc

@@ -32,6 +32,7 @@ for tag, root in (a.split("=") for a in sys.argv[2:]):
         e["valu_busy"] = round(4 * per("SQ_ACTIVE_INST_VALU") / (1024 * cycles), 3)
         e["lane_utilisation"] = round(per("SQ_THREAD_CYCLES_VALU") / (64 * per("SQ_ACTIVE_INST_VALU")), 3)
         e["valu_wave_instructions_per_launch"] = per("SQ_INSTS_VALU")
+        e["executed_lane_ops_per_launch"] = per("SQ_THREAD_CYCLES_VALU")      # one count per active lane per VALU instruction (checked on k_test_issue)
     if n["SQ_WAVE_CYCLES"]:
         e["wait_frac"] = round(per("SQ_WAIT_ANY") / per("SQ_WAVE_CYCLES"), 3)
     if n["TCC_HIT_sum"] and n["TCC_MISS_sum"]:

@@ -114,6 +114,27 @@ def test_intersector_backends_give_the_same_image(ptlib, oracle):
     assert imgs[1]["stats"].tri_tests < imgs[2]["stats"].tri_tests      # the BVH actually prunes
 
 
+def test_anyhit_last_level_changes_the_work_not_the_image(ptlib, oracle):
+    """The product ends a last-level ray at its first hit when no mesh emits; the oracle's counting option restates it:
+    same image bit for bit, same ray trees, fewer node visits / triangle tests; with an emitter in the scene it does nothing."""
+    for name, cam in (("default", ptlib.DEFAULT_CAMERA), ("cornell", ptlib.CORNELL_CAMERA)):
+        data = MG.scene_data(name)
+        sc = ptlib.Scene(None, data)
+        s = ptlib.make_settings(ptlib.make_camera(**cam), 64, 48, 4)
+        out = []
+        for on in (False, True):
+            o = oracle.Scene(data)
+            o.set_flat_bvh(*sc.flat())
+            o.set_anyhit_last_level(on)
+            out.append(o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, 2))
+        a, b = out
+        assert np.array_equal(a["acc"], b["acc"]) and np.array_equal(a["rays"], b["rays"]) and a["stats"].rays == b["stats"].rays
+        if name == "default":
+            assert b["stats"].node_visits < a["stats"].node_visits and b["stats"].tri_tests < a["stats"].tri_tests
+        else:
+            assert b["stats"].node_visits == a["stats"].node_visits           # the Cornell box has a lamp: closest hits throughout
+
+
 def test_math_tables_agree(ptlib, oracle):
     o = oracle.Scene(MG.scene_data("default"))
     s = ptlib.make_settings(ptlib.make_camera(**ptlib.DEFAULT_CAMERA), 64, 64, 5)
