@@ -162,6 +162,8 @@ MIPT_DEV int wide_visit(const RayPre& r, float4 n0, float4 n1, float4 n2, float4
     const uint32_t ex = ngx ? hx : lx, fx = ngx ? lx : hx;
     const uint32_t ey = ngy ? hy : ly, fy = ngy ? ly : hy;
     const uint32_t ez = ngz ? hz : lz, fz = ngz ? lz : hz;
+    // (one v_pk_fma_f32 per axis for the entry + exit plane of a child -- 12 packed FMAs instead of 24 plain ones, clean
+    // code, no extra moves -- measured 1.5 % SLOWER on Default and the grid: profiles/r2/exp_rejected_variants.log)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int sh = 8 * i;
