@@ -403,7 +403,10 @@ bool quantise_node(float* P, const WideChild* ch, int n, const uint32_t* refs) {
     bool failed = false;
     Box nb; for (int i = 0; i < n; i++) if (ch[i].b.valid()) nb.grow(ch[i].b);
     if (!nb.valid()) for (int a = 0; a < 3; a++) nb.mn[a] = nb.mx[a] = 0.f;
-    uint32_t e[3]; uint8_t qlo[3][4] = {}, qhi[3][4] = {};
+    uint32_t e[3]; uint8_t qlo[3][4], qhi[3][4];
+    // a slot without a child gets an inverted box (entry plane behind the exit plane on every axis): the slab test
+    // rejects it by itself (and should rounding ever let it through, its reference is a leaf of zero triangles)
+    memset(qlo, 255, sizeof(qlo)); memset(qhi, 0, sizeof(qhi));
     for (int a = 0; a < 3; a++) {
         const float origin = nb.mn[a];
         // smallest power of two with 255 * scale >= extent; kept inside [2^-60, 2^40] so the product with a ray's
@@ -415,7 +418,7 @@ bool quantise_node(float* P, const WideChild* ch, int n, const uint32_t* refs) {
             bool ok = true;
             const float sc = scale_of((uint32_t)ex);
             for (int i = 0; i < n && ok; i++) {
-                if (!ch[i].b.valid()) { qlo[a][i] = 0; qhi[a][i] = 0; continue; }
+                if (!ch[i].b.valid()) { qlo[a][i] = 255; qhi[a][i] = 0; continue; }
                 int lo = (int)std::floor((ch[i].b.mn[a] - origin) / sc); lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
                 while (lo > 0 && std::fma((float)lo, sc, origin) > ch[i].b.mn[a]) lo--;
                 int hi = (int)std::ceil((ch[i].b.mx[a] - origin) / sc); hi = hi < 0 ? 0 : hi;
@@ -429,9 +432,10 @@ bool quantise_node(float* P, const WideChild* ch, int n, const uint32_t* refs) {
         e[a] = (uint32_t)ex;
     }
     memcpy(P, nb.mn, 12);
-    const uint32_t ebits = e[0] | (e[1] << 8) | (e[2] << 16);
-    memcpy(P + 3, &ebits, 4);
+    // the per-axis scales as floats (powers of two): a visit multiplies them straight into the ray's inverse direction
+    P[3] = scale_of(e[2]);
     for (int a = 0; a < 3; a++) { memcpy(P + 4 + a, qlo[a], 4); memcpy(P + 7 + a, qhi[a], 4); }
+    P[10] = scale_of(e[0]); P[11] = scale_of(e[1]);
     memcpy(P + 12, refs, 16);
     return !failed;
 }
@@ -583,8 +587,12 @@ std::string validate_bvh(BvhOut& out, uint32_t nTris) {
         const float* P = &out.nodes[(size_t)n * 16];
         uint32_t r[4]; memcpy(r, P + 12, 16);
         if (wide) {
-            uint32_t eb; memcpy(&eb, P + 3, 4);
-            for (int a = 0; a < 3; a++) { uint32_t e = (eb >> (8 * a)) & 0xFFu; if (e < 67 || e > 167) return "quantisation exponent out of range"; }
+            const float sc[3] = { P[10], P[11], P[3] };
+            for (int a = 0; a < 3; a++) {          // a power of two inside [2^-60, 2^40]
+                uint32_t b; memcpy(&b, &sc[a], 4);
+                const uint32_t e = b >> 23;
+                if ((b & 0x807FFFFFu) != 0u || e < 67 || e > 167) return "quantisation scale out of range";
+            }
             for (int a = 0; a < 3; a++) if (!std::isfinite(P[a])) return "node origin is not finite";
         }
         for (int c = 0; c < fan; c++) {

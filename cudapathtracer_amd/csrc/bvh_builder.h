@@ -9,10 +9,12 @@
 // Wide layout (BvhParams::nodeWidth = 4, "Q4"): the BVH2 is collapsed to 4 children per node and the child boxes are
 // quantised to 8 bits per plane relative to the node's own box -- still 64 bytes per node, about half as many node
 // visits per ray:
-//   node  = [origin xyz (3 floats)][ex | ey<<8 | ez<<16 : biased exponents, scale = 2^(e-127)]
-//           [qlo.x of children 0..3 (4 bytes)][qlo.y][qlo.z][qhi.x][qhi.y][qhi.z][0][0]
-//           [ref0][ref1][ref2][ref3]                              (unused child = kEmptyRef)
-//   child plane = origin + q * scale, rounded outward so the quantised box contains the child's box.
+//   node  = [origin xyz (3 floats)][scale.z]
+//           [qlo.x of children 0..3 (4 bytes)][qlo.y][qlo.z][qhi.x][qhi.y][qhi.z][scale.x][scale.y]
+//           [ref0][ref1][ref2][ref3]
+//   child plane = origin + q * scale, rounded outward so the quantised box contains the child's box; the scales are
+//   powers of two in [2^-60, 2^40], stored as floats.  An unused child slot holds kEmptyRef (a leaf of zero
+//   references) and an inverted box (qlo = 255, qhi = 0 on every axis), which the slab test rejects by itself.
 #pragma once
 #include <cstdint>
 #include <string>

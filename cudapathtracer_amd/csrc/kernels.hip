@@ -143,10 +143,7 @@ MIPT_DEV HitRec traverse(NodePtr nodes, RefPtr refs, v3 o, v3 d, uint32_t* ldsSt
 #define MIPT_CE(ta_, ra_, tb_, rb_) do { if ((tb_) < (ta_)) { float t_ = (ta_); (ta_) = (tb_); (tb_) = t_; uint32_t r_ = (ra_); (ra_) = (rb_); (rb_) = r_; } } while (0)
 MIPT_DEV int wide_visit(const RayPre& r, float4 n0, float4 n1, float4 n2, float4 n3, float hitT,
                         uint32_t& s0, uint32_t& s1, uint32_t& s2, uint32_t& s3) {
-    const uint32_t eb = __float_as_uint(n0.w);
-    const float ix = r.idir.x * __uint_as_float((eb & 0xFFu) << 23);
-    const float iy = r.idir.y * __uint_as_float(((eb >> 8) & 0xFFu) << 23);
-    const float iz = r.idir.z * __uint_as_float(((eb >> 16) & 0xFFu) << 23);
+    const float ix = r.idir.x * n2.z, iy = r.idir.y * n2.w, iz = r.idir.z * n0.w;      // the node's scales are floats
     const float ox = (n0.x - r.o.x) * r.idir.x, oy = (n0.y - r.o.y) * r.idir.y, oz = (n0.z - r.o.z) * r.idir.z;
     // (picking entry / exit planes by the ray's octant -- one select per axis for all four children instead of a
     // min/max per plane pair -- gives the same values and was measured 5 % slower: the compiler already folds these
@@ -172,7 +169,7 @@ MIPT_DEV int wide_visit(const RayPre& r, float4 n0, float4 n1, float4 n2, float4
         const float tez = ffma((float)((ez >> sh) & 0xFFu), iz, oz), tfz = ffma((float)((fz >> sh) & 0xFFu), iz, oz);
         const float tmin = __builtin_fmaxf(__builtin_fmaxf(tex, tey), __builtin_fmaxf(tez, 0.0f));
         const float tmax = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, hitT));
-        const bool hit = tmin <= tmax && ref[i] != kEmptyRef;
+        const bool hit = tmin <= tmax;        // an empty slot holds an inverted box: no test of its reference needed
         t[i] = hit ? tmin : __builtin_inff();
         n += hit ? 1 : 0;
     }
@@ -525,12 +522,18 @@ MIPT_DEV float4 stack_load(const float4* p) { return *p; }
 template <bool LDS_SCENE>
 MIPT_DEV void load_node(const float4* lds, const float4* glb, uint32_t cur, float4& n0, float4& n1, float4& n2, float4& n3) {
     if constexpr (LDS_SCENE) { const float4* N = lds + (size_t)cur * 4; n0 = N[0]; n1 = N[1]; n2 = N[2]; n3 = N[3]; }
-    else { const float4* N = glb + (size_t)cur * 4; n0 = N[0]; n1 = N[1]; n2 = N[2]; n3 = N[3]; }
+    else {
+        const float4* N = glb + (size_t)cur * 4;
+        n0 = N[0]; n1 = N[1]; n2 = N[2]; n3 = N[3];
+    }
 }
 template <bool LDS_SCENE>
 MIPT_DEV void load_ref(const float4* lds, const float4* glb, uint32_t i, float4& a, float4& b, float4& c) {
     if constexpr (LDS_SCENE) { const float4* T = lds + (size_t)i * 3; a = T[0]; b = T[1]; c = T[2]; }
-    else { const float4* T = glb + (size_t)i * 3; a = T[0]; b = T[1]; c = T[2]; }
+    else {
+        const float4* T = glb + (size_t)i * 3;
+        a = T[0]; b = T[1]; c = T[2];
+    }
 }
 
 // ---- env-map importance sampling (option "estimator" = 1; specification: include/mipt.h, tables built in api.hip) ----
@@ -594,6 +597,7 @@ MIPT_DEV uint32_t wave_sum_u32(uint32_t v) { for (int s = 32; s > 0; s >>= 1) v 
 #define MIPT_PROF(x)
 #endif
 
+#define MIPT_BALLOT(x) __builtin_amdgcn_ballot_w64(x)      // wave64 mask of a per-lane predicate
 template <bool LDS_SCENE, bool WIDE, bool NEE, bool PBS = false>
 __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     constexpr int kSqCap = SqCap<LDS_SCENE>::value;
@@ -647,7 +651,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     const bool skyBlack = A.S.env == nullptr && A.S.skyIntensity == 0.f;
 
     while (true) {
-        const unsigned long long actMask = __ballot(active);
+        const unsigned long long actMask = MIPT_BALLOT(active);
         const uint32_t idle = 64u - (uint32_t)__popcll(actMask);
         const bool starving = idle >= A.refill && sp == 0 && !more;
         const bool pressure = nF + nT > (uint32_t)kSqCap - 32u;      // little room left for rays that terminate next
@@ -707,7 +711,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     }
                 }
             }
-            const unsigned long long sm = NEE ? __ballot(wantEnv) : 0ull, em = NEE ? __ballot(wantEmit) : 0ull;
+            const unsigned long long sm = NEE ? MIPT_BALLOT(wantEnv) : 0ull, em = NEE ? MIPT_BALLOT(wantEmit) : 0ull;
             const uint32_t nEnvRays = (uint32_t)__popcll(sm);
             const uint32_t total = 2u * n + nEnvRays + (uint32_t)__popcll(em);
             if (sp + total > A.cap) {
@@ -824,7 +828,8 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
         }
 
         // ---- C. done when nothing is in flight, parked, stacked or left in the frame --------------------------------
-        const uint32_t nActive = (uint32_t)__popcll(__ballot(active));
+        const unsigned long long roundActive = MIPT_BALLOT(active);
+        const uint32_t nActive = (uint32_t)__popcll(roundActive);
         if (nActive == 0u) {
             if (nF + nT == 0u) break;
             continue;
@@ -840,7 +845,9 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
         bool firstVisit = true;                 // every round makes progress: the first visit is unconditional
         while (true) {
             const bool go = active && !(cur & kLeaf);
-            const uint32_t nGo = (uint32_t)__popcll(__ballot(go));
+            // ballot of the compare itself, masked with the round's active mask on the scalar side (a ballot of the
+            // combined bool costs a v_cndmask + v_cmp_ne per iteration)
+            const uint32_t nGo = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)cur >= 0) & roundActive);
             if (nGo == 0u || (!firstVisit && nGo < minDescend)) break;
             firstVisit = false;
             if (go) {
@@ -848,13 +855,27 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 float4 n0, n1, n2, n3;
                 load_node<LDS_SCENE>(ldsNodes, A.S.nodes, cur, n0, n1, n2, n3);
                 if constexpr (WIDE) {
+                    // keep the four loads of the node together: without the child references in the hit test the
+                    // compiler sinks their load behind it, a second dependent round trip per visit
+                    asm volatile("" : "+v"(n3.w));
                     uint32_t s0_, s1_, s2_, s3_;
                     const int nh = wide_visit(r, n0, n1, n2, n3, h.t, s0_, s1_, s2_, s3_);
                     if (nh == 0) { MIPT_STACK_POP(lstk, deep, tsp, cur); }
                     else {
-                        if (nh > 3) MIPT_STACK_PUSH(lstk, deep, tsp, s3_);
-                        if (nh > 2) MIPT_STACK_PUSH(lstk, deep, tsp, s2_);
-                        if (nh > 1) MIPT_STACK_PUSH(lstk, deep, tsp, s1_);
+                        if (tsp <= kLdsStack - 3) {
+                            // all three slots above the top are in LDS: write them without a branch per entry.  Slot j gets
+                            // s[nh-1-j] (farthest deepest, second-nearest on top); what lands above the new top is never read.
+                            const uint32_t a0 = nh == 4 ? s3_ : (nh == 3 ? s2_ : s1_);
+                            const uint32_t a1 = nh == 4 ? s2_ : s1_;
+                            uint32_t* const top = lstk + tsp * kBlock;
+                            top[0] = a0; top[kBlock] = a1; top[2 * kBlock] = s1_;
+                            tsp += nh - 1;
+                        } else
+                        {
+                            if (nh > 3) MIPT_STACK_PUSH(lstk, deep, tsp, s3_);
+                            if (nh > 2) MIPT_STACK_PUSH(lstk, deep, tsp, s2_);
+                            if (nh > 1) MIPT_STACK_PUSH(lstk, deep, tsp, s1_);
+                        }
                         cur = s0_;
                     }
                 } else {
@@ -886,6 +907,8 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 for (uint32_t i = first; i < first + cnt; i++) {
                     float4 a, b, c;
                     load_ref<LDS_SCENE>(ldsRefs, A.S.refs, i, a, b, c);
+                    // all three loads of the record at once (the compiler sinks the vertex behind the determinant test)
+                    if constexpr (!LDS_SCENE) asm volatile("" : "+v"(a.x));
                     float tt, uu, vv; bool ff;
                     int id = (int)__float_as_uint(a.w);
                     if (mt_test(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) {
@@ -900,10 +923,10 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 if (A.S.emissiveMeshes == 0u) { if (h.tri >= 0 && (32u - (uint32_t)__clz((int)node)) >= A.F.maxDepth) cur = kTerm; }
             }
         }
-        MIPT_PROF(pf[0]++; pf[1] += (uint32_t)__popcll(__ballot(active)); pf[2] += wave_max_u32(myNodes); pf[3] += wave_sum_u32(myNodes);
+        MIPT_PROF(pf[0]++; pf[1] += (uint32_t)__popcll(MIPT_BALLOT(active)); pf[2] += wave_max_u32(myNodes); pf[3] += wave_sum_u32(myNodes);
                   pf[4] += wave_max_u32(myTris); pf[5] += wave_sum_u32(myTris);)
         bool fin = active && cur == kTerm;
-        unsigned long long fm = __ballot(fin);
+        unsigned long long fm = MIPT_BALLOT(fin);
         if (fm) {
             const uint32_t level = 31u - (uint32_t)__clz((int)node);             // root = 1 -> level 0
             const bool term = h.tri < 0 || level + 1 >= A.F.maxDepth              // children would have ttl 0 (CUDATracerProg.cu:433)
@@ -914,10 +937,10 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                                             : (shadow || !(__float_as_uint(h.u) >> 31) || (NEE && (pix & kNoEmitBit)));
                 if (dead) { active = false; fin = false; }
             }
-            fm = __ballot(fin);
+            fm = MIPT_BALLOT(fin);
             // no room: stay terminated-but-unparked until the queue has been drained
             fin = fin && nF + nT + (uint32_t)__popcll(fm & below) < (uint32_t)kSqCap;
-            const unsigned long long mF = __ballot(fin && !term), mT = __ballot(fin && term);
+            const unsigned long long mF = MIPT_BALLOT(fin && !term), mT = MIPT_BALLOT(fin && term);
             if (fin) {
                 const uint32_t e = term ? (uint32_t)kSqCap - 1u - (nT + (uint32_t)__popcll(mT & below)) : nF + (uint32_t)__popcll(mF & below);
                 v3 P = o + d * h.t;                                   // tail of NearestIntersectSubset (:294)

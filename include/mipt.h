@@ -127,9 +127,10 @@ int  mipt_scene_refit(mipt_scene*, const mipt_scene_desc* desc);
 int  mipt_scene_get_bvh(const mipt_scene*, float* nodes, uint32_t* n_nodes, float* refs, uint32_t* n_refs);
 uint32_t mipt_scene_triangle_count(const mipt_scene*);
 uint32_t mipt_scene_bvh_width(const mipt_scene*);           /* 2 or 4: node layout of mipt_scene_get_bvh's `nodes` (4-wide: 16 floats =
-                                                             * [origin xyz][ex|ey<<8|ez<<16][qlo.x qlo.y qlo.z qhi.x qhi.y qhi.z: 4 bytes each,
-                                                             * one per child][0][0][ref0..ref3]; plane = origin + q * 2^(e-127); unused child
-                                                             * = 0x80000000) */
+                                                             * [origin xyz][scale.z][qlo.x qlo.y qlo.z qhi.x qhi.y qhi.z: 4 bytes each,
+                                                             * one per child][scale.x][scale.y][ref0..ref3]; plane = origin + q * scale,
+                                                             * scales = powers of two as floats; unused child = 0x80000000 with an
+                                                             * inverted box, qlo = 255 / qhi = 0) */
 int  mipt_scene_bvh_was_cached(const mipt_scene*);
 /* Option "estimator" (mipt_set_option; not in the reference, which has no light sampling):
  *   0 = the reference's estimator: every radiance term arrives through a traced child ray (CUDATracerProg.cu:426-541);

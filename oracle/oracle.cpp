@@ -559,9 +559,9 @@ Hit isect_flat(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false)
     }
     return best;
 }
-// --- product 4-wide quantised layout: node = [origin xyz][ex|ey<<8|ez<<16][qlo.x qlo.y qlo.z qhi.x qhi.y qhi.z: one byte
-//     per child][0][0][ref0..ref3].  The ray is moved into the node's quantised frame exactly as the kernel does
-//     (kernels.hip wide_visit): t = q * (idir * 2^(e-127)) + (origin - o) * idir.  Hit children are visited nearest
+// --- product 4-wide quantised layout: node = [origin xyz][scale.z][qlo.x qlo.y qlo.z qhi.x qhi.y qhi.z: one byte
+//     per child][scale.x][scale.y][ref0..ref3], scales = powers of two as floats.  The ray is moved into the node's
+//     quantised frame exactly as the kernel does (kernels.hip wide_visit): t = q * (idir * scale) + (origin - o) * idir.  Hit children are visited nearest
 //     first (5-exchange sorting network, swap iff tb < ta), the others pushed farthest first. ---
 inline float ubits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false) {
@@ -583,10 +583,7 @@ Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false
             if (anyhit && best.tri >= 0) return best;          // the product's last-level shortcut: the leaf is finished, then the ray ends
         } else {
             const float* N = &s.fnodes[(size_t)cur * 16]; c->nodes++;
-            const uint32_t eb = (uint32_t)fbits(N[3]);
-            const float ix = r.idir.x * ubits((eb & 0xFFu) << 23);
-            const float iy = r.idir.y * ubits(((eb >> 8) & 0xFFu) << 23);
-            const float iz = r.idir.z * ubits(((eb >> 16) & 0xFFu) << 23);
+            const float ix = r.idir.x * N[10], iy = r.idir.y * N[11], iz = r.idir.z * N[3];
             const float ox = (N[0] - r.o.x) * r.idir.x, oy = (N[1] - r.o.y) * r.idir.y, oz = (N[2] - r.o.z) * r.idir.z;
             const uint32_t lx = (uint32_t)fbits(N[4]), ly = (uint32_t)fbits(N[5]), lz = (uint32_t)fbits(N[6]);
             const uint32_t hx = (uint32_t)fbits(N[7]), hy = (uint32_t)fbits(N[8]), hz = (uint32_t)fbits(N[9]);
@@ -599,7 +596,7 @@ Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false
                 float tlz = ffma((float)((lz >> sh) & 0xFFu), iz, oz), thz = ffma((float)((hz >> sh) & 0xFFu), iz, oz);
                 float tmin = fmax_(fmax_(fmin_(tlx, thx), fmin_(tly, thy)), fmax_(fmin_(tlz, thz), 0.0f));
                 float tmax = fmin_(fmin_(fmax_(tlx, thx), fmax_(tly, thy)), fmin_(fmax_(tlz, thz), best.t));
-                const bool hit = tmin <= tmax && ref[i] != 0x80000000u;
+                const bool hit = tmin <= tmax;      // empty slots carry an inverted box (and a zero-triangle leaf reference)
                 t[i] = hit ? tmin : INFINITY;
                 n += hit ? 1 : 0;
             }
@@ -1094,11 +1091,13 @@ int orc_check_flat_bvh(const orc_scene* s, char* msg, uint32_t cap) {
             st.push_back((uint32_t)fbits(N[12])); st.push_back((uint32_t)fbits(N[13]));
             if (s->fwidth == 4) {
                 st.push_back((uint32_t)fbits(N[14])); st.push_back((uint32_t)fbits(N[15]));
-                const uint32_t eb = (uint32_t)fbits(N[3]);
-                for (int a = 0; a < 3; a++) { uint32_t e = (eb >> (8 * a)) & 0xFFu; if (e < 67 || e > 167) return fail(11, "quantisation exponent out of range"); }
+                const uint32_t sb[3] = { (uint32_t)fbits(N[10]), (uint32_t)fbits(N[11]), (uint32_t)fbits(N[3]) };      // scale x, y, z
+                for (int a = 0; a < 3; a++) { uint32_t e = sb[a] >> 23; if ((sb[a] & 0x807FFFFFu) || e < 67 || e > 167) return fail(11, "quantisation scale out of range"); }
                 for (int i = 0; i < 4; i++) for (int a = 0; a < 3; a++) {
                     uint32_t lo = ((uint32_t)fbits(N[4 + a]) >> (8 * i)) & 0xFFu, hi = ((uint32_t)fbits(N[7 + a]) >> (8 * i)) & 0xFFu;
-                    if ((uint32_t)fbits(N[12 + i]) != 0x80000000u && lo > hi) return fail(12, "inverted quantised child box");
+                    const bool empty = (uint32_t)fbits(N[12 + i]) == 0x80000000u;
+                    if (!empty && lo > hi) return fail(12, "inverted quantised child box");
+                    if (empty && !(lo == 255u && hi == 0u)) return fail(13, "empty child slot without an inverted box");
                 }
             }
         }
