@@ -842,6 +842,11 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
         // tested and terminated rays replaced -- which bounds the tail of the loop (profiles/r1/lane_profile_*.log).
         // minDescend = 1 is the classic while-while.
         const uint32_t minDescend = A.minDescend < (nActive + 1u) / 2u ? A.minDescend : (nActive + 1u) / 2u;   // thin waves: scale down
+        // LDS-resident scenes: while too few rays have ended for a refill to follow, the wave goes round the node loop and
+        // the leaf test again before it parks anybody (Cornell +2.7 %; on the 4-wide kernels the extra loop level costs
+        // registers and 9-13 %: profiles/r2/exp_subround.log)
+        bool again;
+        do {
         bool firstVisit = true;                 // every round makes progress: the first visit is unconditional
         while (true) {
             const bool go = active && !(cur & kLeaf);
@@ -923,6 +928,12 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                 if (A.S.emissiveMeshes == 0u) { if (h.tri >= 0 && (32u - (uint32_t)__clz((int)node)) >= A.F.maxDepth) cur = kTerm; }
             }
         }
+        again = false;
+        if constexpr (LDS_SCENE && !NEE) {      // (the light-sampling variants are short of registers as it is)
+            const uint32_t nFinNow = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cur == kTerm) & roundActive);
+            again = nFinNow + (64u - nActive) < A.refill && nFinNow < nActive;
+        }
+        } while (again);
         MIPT_PROF(pf[0]++; pf[1] += (uint32_t)__popcll(MIPT_BALLOT(active)); pf[2] += wave_max_u32(myNodes); pf[3] += wave_sum_u32(myNodes);
                   pf[4] += wave_max_u32(myTris); pf[5] += wave_sum_u32(myTris);)
         bool fin = active && cur == kTerm;
