@@ -145,6 +145,7 @@ lib.mipt_rgbe_decode.argtypes = [_vp, C.c_size_t, _vp, C.POINTER(C.c_uint32), C.
 lib.mipt_rgbe_encode.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp, C.c_size_t]
 lib.mipt_rgbe_encode.restype = C.c_size_t
 lib.mipt_test_math.argtypes = [_vp, C.c_int, _vp, _vp, C.c_uint32, _vp]
+lib.mipt_test_rcp_sweep.argtypes = [_vp, C.c_int, C.POINTER(C.c_uint64)]
 lib.mipt_test_issue.argtypes = [_vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(IssueResult)]
 
 
@@ -437,6 +438,12 @@ class Tracer:
         out = np.zeros_like(a)
         self._chk(lib.mipt_test_math(self.h, fn, _ptr(a), _ptr(b), len(a), _ptr(out)), "test_math")
         return out
+
+    def test_rcp_sweep(self, steps):
+        """(compared, differing, first differing input bits, differing by > 1 ulp) of rcp_newton<steps> vs 1.0f / x"""
+        out = (C.c_uint64 * 4)()
+        self._chk(lib.mipt_test_rcp_sweep(self.h, steps, out), "test_rcp_sweep")
+        return tuple(int(v) for v in out)
 
     def test_issue(self, blocks_per_cu, iters, packed=0):
         """VALU issue calibration (csrc/microbench.hip): returns an IssueResult."""

@@ -322,6 +322,9 @@ int gather_geometry(mipt_tracer* t, const mipt_scene_desc* d, std::vector<TriPos
                 uint32_t vi = md.indices[i + k];
                 if (vi >= md.vertexCnt) return fail(t, MIPT_E_INVALID, "vertex index out of range");
                 memcpy(tp.v[k], md.vertices[vi].position, 12);
+                // finite and below 2^40: the integrator's short reciprocals (kernels.hip mt_test<true>) are bit-exact for
+                // |det| <= 2^100, which unit-scale directions and edges of at most 2^41 keep far away
+                for (int a = 0; a < 3; a++) if (!(std::fabs(tp.v[k][a]) < 1.099511627776e12f)) return fail(t, MIPT_E_INVALID, "vertex coordinate not finite or beyond 2^40");
                 // unit vertex normal, as the reference normalises at hit time (CUDATracerProg.cu:290-293)
                 const float* n = md.vertices[vi].normal;
                 float len = sqrtf(hdot(n, n));
@@ -1223,6 +1226,27 @@ int mipt_test_issue(mipt_tracer* t, int packed, uint32_t blocks_per_cu, uint32_t
         out->median_cycles = (double)cyc[waves / 2]; out->max_cycles = (double)cyc[waves - 1];
         out->median_realtime_ticks = (double)rt[waves / 2];
         hipEventDestroy(a); hipEventDestroy(b); hipFree(stamps); hipFree(sink);
+        return MIPT_OK;
+    });
+}
+
+// Exhaustive comparison of the integrator's short reciprocal (device_math.h rcp_newton<steps>) with the compiler's IEEE
+// division over every float of magnitude 2^-100 .. 2^100.  out[0] compared, out[1] differing, out[2] first differing input
+// (bits, or 0), out[3] differing by more than one unit in the last place.
+int mipt_test_rcp_sweep(mipt_tracer* t, int steps, uint64_t out[4]) {
+    return guarded(t, [&]() -> int {
+        if (!t || !out || steps < 0 || steps > 3) return fail(t, MIPT_E_INVALID, "test_rcp_sweep: steps 0..3");
+        if (use(t)) return MIPT_E_HIP;
+        unsigned long long* d = nullptr;
+        HIPCHK(t, hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
+        const unsigned long long init[4] = { 0ull, 0ull, ~0ull, 0ull };
+        HIPCHK(t, hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice));
+        launch_test_rcp_sweep(steps, t->numCU * 8, d, t->stream);
+        HIPCHK(t, hipStreamSynchronize(t->stream));
+        unsigned long long h[4];
+        HIPCHK(t, hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+        hipFree(d);
+        out[0] = h[0]; out[1] = h[1]; out[2] = h[2] == ~0ull ? 0ull : (h[2] & 0xFFFFFFFFull); out[3] = h[3];
         return MIPT_OK;
     });
 }

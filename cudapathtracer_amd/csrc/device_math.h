@@ -30,6 +30,16 @@ MIPT_DEV v3 cross3(v3 a, v3 b) {
 MIPT_DEV float length3(v3 a) { return __builtin_sqrtf(dot3(a, a)); }
 MIPT_DEV v3 normalize3(v3 a) { return (a * 1.f) / __builtin_sqrtf(dot3(a, a)); }
 MIPT_DEV v3 reflect3(v3 i, v3 n) { return i - n * dot3(n, i) * 2.0f; }
+// 1 / x, correctly rounded, for |x| in [2^-100, 2^100] (no scaling, no special cases): the hardware estimate (1 ulp) and
+// `steps` Newton corrections in FMA form.  mipt_test_rcp_sweep compares it with the compiler's full IEEE expansion of
+// 1.0f / x (v_div_scale x2, v_rcp, 5 FMAs, v_div_fmas, v_div_fixup: 11 instructions) over every float in that range.
+template <int STEPS>
+MIPT_DEV float rcp_newton(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+#pragma unroll
+    for (int i = 0; i < STEPS; i++) { const float e = __builtin_fmaf(-x, r, 1.0f); r = __builtin_fmaf(e, r, r); }
+    return r;
+}
 MIPT_DEV float saturatef(float x) { return !(x > 0.f) ? 0.f : (x > 1.f ? 1.f : x); }
 MIPT_DEV v3 xyz(float4 f) { return mk3(f.x, f.y, f.z); }
 

@@ -94,6 +94,7 @@ void launch_accumulate(float* sample, float* acc, unsigned char* ldr, float weig
 void launch_tonemap(const float* acc, float scale, uint32_t npix, unsigned char* ldr, hipStream_t s);
 void launch_trace_rays(const SceneDev& S, const float* o, const float* d, uint32_t n, void* hits, hipStream_t s);
 void launch_test_issue(int packed, uint32_t iters, int blocks, unsigned long long* stamps, float* sink, hipStream_t s);   // microbench.hip
+void launch_test_rcp_sweep(int steps, int blocks, unsigned long long* out, hipStream_t s);      // microbench.hip
 void launch_test_math(int fn, const float* a, const float* b, uint32_t n, float* out, hipStream_t s);
 
 }  // namespace mipt

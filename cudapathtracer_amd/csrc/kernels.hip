@@ -31,12 +31,18 @@ struct HitRec { float t, u, v; int ref; int tri; bool front; };   // ref = refer
 struct RayPre { v3 o, d, idir, ood; };
 
 // CUDATracerProg.cu:567-574
+// SHORT_RCP: the reciprocals through rcp_newton<1> (3 instructions instead of the 11 of an IEEE division; bit-identical for
+// magnitudes in [2^-100, 2^100], mipt_test_rcp_sweep) -- for directions the integrator generated itself, which are of
+// unit scale; caller-supplied rays (k_trace_rays) keep the full division.
+template <bool SHORT_RCP = false>
 MIPT_DEV RayPre ray_pre(v3 o, v3 d) {
     const float ooeps = 8.271806125530277e-25f;   // exp2f(-80)
     RayPre r; r.o = o; r.d = d;
-    r.idir.x = 1.0f / (__builtin_fabsf(d.x) > ooeps ? d.x : __builtin_copysignf(ooeps, d.x));
-    r.idir.y = 1.0f / (__builtin_fabsf(d.y) > ooeps ? d.y : __builtin_copysignf(ooeps, d.y));
-    r.idir.z = 1.0f / (__builtin_fabsf(d.z) > ooeps ? d.z : __builtin_copysignf(ooeps, d.z));
+    const float gx = __builtin_fabsf(d.x) > ooeps ? d.x : __builtin_copysignf(ooeps, d.x);
+    const float gy = __builtin_fabsf(d.y) > ooeps ? d.y : __builtin_copysignf(ooeps, d.y);
+    const float gz = __builtin_fabsf(d.z) > ooeps ? d.z : __builtin_copysignf(ooeps, d.z);
+    if constexpr (SHORT_RCP) { r.idir.x = rcp_newton<1>(gx); r.idir.y = rcp_newton<1>(gy); r.idir.z = rcp_newton<1>(gz); }
+    else { r.idir.x = 1.0f / gx; r.idir.y = 1.0f / gy; r.idir.z = 1.0f / gz; }
     r.ood = mk3(o.x * r.idir.x, o.y * r.idir.y, o.z * r.idir.z);
     return r;
 }
@@ -57,11 +63,14 @@ MIPT_DEV bool slab(const RayPre& r, float mnx, float mny, float mnz, float mxx, 
 // Moller-Trumbore on a precomputed (v0, e1, e2) reference: CUDATracerProg.cu:232-263.  Strict t < tmin as in the
 // reference; an exact tie goes to the lower global triangle id (the reference lets the first triangle found win, which
 // across meshes is the lower mesh index), so the closest hit does not depend on the BVH's shape.
+// SHORT_RCP: 1 / det through rcp_newton<1> (see ray_pre): |det| >= 2^-23 here, and <= 2^84 for unit-scale directions and
+// the vertex coordinates mipt_scene_create accepts (below 2^40).
+template <bool SHORT_RCP = false>
 MIPT_DEV bool mt_test(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, int id, int bestId, float& t_, float& u_, float& v_, bool& front) {
     v3 pvec = cross3(d, e2);
     float det = dot3(e1, pvec);
     if (__builtin_fabsf(det) < FLT_EPSILON) return false;
-    float invDet = 1 / det;
+    float invDet = SHORT_RCP ? rcp_newton<1>(det) : 1 / det;
     v3 tvec = o - v0;
     float u = dot3(tvec, pvec) * invDet;
     if (u < 0 || u > 1) return false;
@@ -601,6 +610,7 @@ MIPT_DEV uint32_t wave_sum_u32(uint32_t v) { for (int s = 32; s > 0; s >>= 1) v 
 template <bool LDS_SCENE, bool WIDE, bool NEE, bool PBS = false>
 __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     constexpr int kSqCap = SqCap<LDS_SCENE>::value;
+    constexpr bool kShortRcp = true;       // 3-instruction reciprocals for the rays this kernel generates itself (ray_pre, mt_test): +2-3 %
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
     __shared__ float sqMem[(kBlock / 64) * kSqWords * kSqCap];
     __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneVec : 1];
@@ -634,7 +644,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     bool active = false;
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), beta = mk3(0, 0, 0);
     uint32_t pix = 0, node = 1, s0 = 0;
-    RayPre r = ray_pre(o, d);
+    RayPre r = ray_pre<false>(o, d);
     HitRec h; h.t = __builtin_inff(); h.u = h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
     uint32_t cur = kTerm;
     uint32_t* const lstk = ldsStack + threadIdx.x;
@@ -813,7 +823,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                         o = xyz(ra); d = mk3(ra.w, rb.x, rb.y); beta = mk3(rb.z, rb.w, rc.x);
                         pix = __float_as_uint(rc.y); node = __float_as_uint(rc.z); s0 = __float_as_uint(rc.w);
                     }
-                    r = ray_pre(o, d);
+                    r = ray_pre<kShortRcp>(o, d);
                     h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
                     tsp = 0;
                     if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, kTerm); else MIPT_STACK_PUSH(lstk, deep, tsp, kTerm);
@@ -916,7 +926,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
                     if constexpr (!LDS_SCENE) asm volatile("" : "+v"(a.x));
                     float tt, uu, vv; bool ff;
                     int id = (int)__float_as_uint(a.w);
-                    if (mt_test(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) {
+                    if (mt_test<kShortRcp>(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) {
                         h.t = tt; h.u = uu; h.v = vv; h.front = ff; h.ref = (int)i; h.tri = id;
                         h.u = __uint_as_float(__float_as_uint(uu) | (__float_as_uint(c.w) << 30));     // flags bit 1 -> sign bit
                     }

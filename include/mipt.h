@@ -264,6 +264,11 @@ typedef struct {
     double clock_ghz;            /* median over waves of cycles / (ticks * 10 ns): the clock the chip held during the loop */
 } mipt_issue_result;
 /* packed 0: v_fma_f32; 1: v_pk_fma_f32 (two FMAs per lane per instruction) */
+/* Exhaustive check of the integrator's short reciprocal (rcp + `steps` Newton corrections in FMA form, used for a ray's
+ * inverse direction and the triangle test's 1 / det) against IEEE division over every float of magnitude 2^-100 .. 2^100:
+ * out[0] = values compared, out[1] = values whose bits differ, out[2] = first differing input (bits), out[3] = differing
+ * by more than one unit in the last place.  (No counterpart in the reference.) */
+int  mipt_test_rcp_sweep(mipt_tracer*, int steps, uint64_t out[4]);
 int  mipt_test_issue(mipt_tracer*, int packed, uint32_t blocks_per_cu, uint32_t iters, mipt_issue_result* out);
 
 #ifdef __cplusplus

@@ -3,6 +3,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -65,6 +66,11 @@ def test_host_only_scene_errors(ptlib):
     i2[0] = 99
     with pytest.raises(ptlib.MiptError):
         ptlib.Scene(None, ptlib.SceneData([(v, i2, m)], data.sky))   # vertex index out of range
+    for bad_coord in (np.inf, np.nan, 2.0e12):       # vertex coordinates must be finite and below 2^40 (include/mipt.h)
+        v2 = v.copy()
+        v2["position"][1, 2] = bad_coord
+        with pytest.raises(ptlib.MiptError):
+            ptlib.Scene(None, ptlib.SceneData([(v2, i, m)], data.sky))
     with pytest.raises(ptlib.MiptError):
         ptlib.Scene(None, data, builder=7)
     with pytest.raises(ptlib.MiptError):
