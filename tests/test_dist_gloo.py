@@ -76,6 +76,64 @@ def test_two_rank_sample_striding_matches_single_rank(tmp_path, ptlib, oracle):
     assert np.allclose(got[..., :3], ref[..., :3], rtol=1e-5, atol=1e-6)      # summation order differs
 
 
+GPU_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+import cudapathtracer_amd as pt
+from cudapathtracer_amd.dist import frames_for_rank, reduce_accumulation
+t = pt.Tracer(0)                                   # every rank on the one GPU of the box: the tracer before the process group
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+sc = pt.Scene(t, pt.builtin_scene(0))
+W, H, N = 96, 64, 7
+s = pt.make_settings(pt.make_camera(**pt.CORNELL_CAMERA), W, H, 4)
+first, count, stride = frames_for_rank(0, N, rank, world)
+acc = t.malloc(W * H * 16)
+t.memset(acc, 0, W * H * 16)
+t.render(sc, s, first, count, acc, None, frame_stride=stride, sum_mode=1)      # the integrator adds straight into acc
+t.synchronize()
+rays = t.counters().rays
+mean = reduce_accumulation(torch.from_numpy(t.download(acc, (H, W, 4), np.float32)), N, dst=0)
+tot = torch.tensor([rays], dtype=torch.int64)
+dist.reduce(tot, 0)
+if rank == 0:
+    np.save(os.environ["OUT"], mean.numpy())
+    open(os.environ["OUT"] + ".rays", "w").write(str(int(tot[0])))
+else:
+    assert mean is None
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_two_libmipt_ranks_render_the_frames_one_rank_renders(tmp_path, tracer, ptlib):
+    """two processes, each with its own libmipt tracer (both on the box's one GPU), sample striding + reduce through
+    dist.py: the mean equals the single-tracer running mean, the rays add up to the same total"""
+    out = str(tmp_path / "mean.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(GPU_WORKER)
+    env = dict(os.environ, REPO=ROOT, OUT=out, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    W, H, N = 96, 64, 7
+    sc = ptlib.Scene(tracer, ptlib.builtin_scene(0))
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), W, H, 4)
+    acc = tracer.malloc(W * H * 16)
+    tracer.memset(acc, 0, W * H * 16)
+    tracer.reset_counters()
+    tracer.render(sc, s, 0, N, acc, None)
+    tracer.synchronize()
+    ref = tracer.download(acc, (H, W, 4), np.float32)
+    assert int(open(out + ".rays").read()) == tracer.counters().rays
+    assert (got[..., 3] == 1).all()
+    assert np.allclose(got[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5) and ref[..., :3].mean() > 0.01
+    tracer.free(acc)
+
+
 PROGRESSIVE_WORKER = r"""
 import os, sys
 import numpy as np, torch, torch.distributed as dist
