@@ -475,7 +475,10 @@ public:
             else { refs[i] = (uint32_t)(N4.size() / 16); need = std::max(need, build(ch[i].ref, level + 1)); }
         }
         quantise(self, ch, n, refs);
-        return need + (n > 0 ? (uint32_t)n - 1u : 0u);
+        // every inner node is charged three pushes, whatever its fan-out: an empty slot is rejected by its inverted box, but
+        // should rounding ever let one through (all three axes absorbed: a far, tiny node) its zero-triangle reference
+        // is pushed like any other and must find room
+        return need + (n > 0 ? 3u : 0u);
     }
 
 private:
@@ -620,6 +623,7 @@ std::string validate_bvh(BvhOut& out, uint32_t nTris) {
             if (r[c] & kLeafFlag) { if (!wide || r[c] != kEmptyRef) kids++; }
             else { kids++; below = std::max(below, need[r[c]]); }
         }
+        if (wide && kids > 0) kids = 4;                              // as Collapser::build: empty slots are charged too
         need[n] = below + (kids > 0 ? (uint32_t)kids - 1u : 0u);
     }
     out.maxDepth = deepest;
