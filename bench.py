@@ -72,6 +72,8 @@ def parse():
     p.add_argument("--integrator", type=int, default=0, help="0 persistent wave stacks (default), 1 level-synchronous queues")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (default); gloo = rehearsal of the N>1 flow through host memory")
     p.add_argument("--node-width", type=int, default=0, help="BVH node layout: 0 library default, 2 fp32 BVH2, 4 quantised 4-wide")
+    p.add_argument("--tri-cost", type=float, default=0.0, help="SAH triangle cost of the BVH build (0 = library default; tuning experiments)")
+    p.add_argument("--max-leaf", type=int, default=0, help="largest leaf of the BVH build (0 = library default 4; tuning experiments)")
     p.add_argument("--pipeline", type=int, default=1, help="1 (default): consecutive frames alternate between two streams so a frame's tail overlaps the next frame; 0: one stream")
     p.add_argument("--estimator", type=int, default=0, help="0 the reference's estimator (default, the parity configuration); 1 env-map / emitter sampling with occlusion rays; 2 VNDF-sampled specular + cosine-weighted diffuse lobes; 3 both")
     p.add_argument("--option", action="append", default=[], help="key=value passed to mipt_set_option (tuning experiments)")
@@ -183,12 +185,12 @@ def build_scene(pt, a, name, t, rank, multi, dist):
     if name == "grid" and multi:
         # 10 M triangles: rank 0 builds the BVH and writes the cache file, the others load it instead of building eight times
         cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mipt_bench_grid{a.grid_n}_w{a.node_width}.bvh")
-        sc = pt.Scene(t, data, node_width=a.node_width, bvh_cache=cache) if rank == 0 else None
+        sc = pt.Scene(t, data, node_width=a.node_width, bvh_cache=cache, tri_cost=a.tri_cost, max_leaf=a.max_leaf) if rank == 0 else None
         dist.barrier()
         if rank != 0:
-            sc = pt.Scene(t, data, node_width=a.node_width, bvh_cache=cache)
+            sc = pt.Scene(t, data, node_width=a.node_width, bvh_cache=cache, tri_cost=a.tri_cost, max_leaf=a.max_leaf)
     else:
-        sc = pt.Scene(t, data, node_width=a.node_width)
+        sc = pt.Scene(t, data, node_width=a.node_width, tri_cost=a.tri_cost, max_leaf=a.max_leaf)
     return data, settings, sc, W, H, depth
 
 
@@ -280,7 +282,7 @@ def run_workload(name, a, ctx, cpu_seconds):
         if cpu_seconds > 0:
             threads = min(os.cpu_count() or 1, 16)
             cpu = oracle_sample(pt, data, (nodes, refs), sc.bvh_width, settings, cpu_seconds if world == 1 else min(cpu_seconds, 3.0), threads, a.estimator)
-        default_config = (W, H, depth) == WORKLOADS[name][1:] and (name != "grid" or a.grid_n == 2236) and not a.node_width and not a.estimator and not a.option and a.integrator == 0 and a.pipeline == 1
+        default_config = (W, H, depth) == WORKLOADS[name][1:] and (name != "grid" or a.grid_n == 2236) and not a.node_width and not a.tri_cost and not a.max_leaf and not a.estimator and not a.option and a.integrator == 0 and a.pipeline == 1
         pmc = pmc_for(name, default_config)
         working_set = nn * 64 + nr * 48
         roof = None
