@@ -610,7 +610,7 @@ MIPT_DEV uint32_t wave_sum_u32(uint32_t v) { for (int s = 32; s > 0; s >>= 1) v 
 #define MIPT_BALLOT(x) __builtin_amdgcn_ballot_w64(x)      // wave64 mask of a per-lane predicate
 template <bool LDS_SCENE, bool WIDE, bool NEE, bool PBS = false>
 // 4 blocks per CU = 4 waves per SIMD at the 128-VGPR cap (4-5 spills outside the hot loops).  Three blocks with the
-// ~145 VGPRs the compiler would like (no spills) run 0.85x; five at 96 VGPRs spill 30 registers inside the loops, 0.5-0.6x.
+// ~145 VGPRs the compiler would like (no spills) run 0.85x; five at 96 VGPRs and 32 KiB of LDS spill 35-40 registers, 0.6-0.7x.
 __global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
     constexpr int kSqCap = SqCap<LDS_SCENE>::value;
     constexpr bool kShortRcp = true;       // 3-instruction reciprocals for the rays this kernel generates itself (ray_pre, mt_test): +2-3 %
