@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -368,7 +369,12 @@ void fill_materials(const mipt_scene_desc* d, std::vector<float>& mats) {
         const mipt_material& mm = d->meshes[m].material; float* M = &mats[(size_t)m * 12];
         M[0] = mm.color[0]; M[1] = mm.color[1]; M[2] = mm.color[2]; M[3] = mm.roughness;
         M[4] = mm.metallic; M[5] = mm.opacity; M[6] = mm.n; M[7] = mm.emissiveStrength;
-        M[8] = mm.emissiveColor[0]; M[9] = mm.emissiveColor[1]; M[10] = mm.emissiveColor[2]; M[11] = 0.f;
+        M[8] = mm.emissiveColor[0]; M[9] = mm.emissiveColor[1]; M[10] = mm.emissiveColor[2];
+        // Schlick's r0 (CUDATracerProg.cu:463-481), the same fp32 operations the kernel used to run per hit: it depends on the
+        // material alone -- entering or leaving only swaps n1 and n2, which negates the quotient exactly before it is squared
+        float n2 = mm.n; n2 += FLT_EPSILON;
+        float r0 = (1.f - n2) / (1.f + n2); r0 *= r0;
+        M[11] = r0;
     }
 }
 

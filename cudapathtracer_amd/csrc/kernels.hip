@@ -23,7 +23,6 @@ constexpr uint32_t kLeaf = 0x80000000u;
 constexpr uint32_t kTerm = 0xFFFFFFFFu;
 constexpr int kStackCap = 64;      // == kMaxBvhDepth of the builder
 constexpr int kWideStackCap = 96;  // == kMaxWideStack of the builder (4-wide nodes push up to three entries per level)
-constexpr uint32_t kEmptyRef = 0x80000000u;
 constexpr int kLdsStack = 12;      // entries per lane kept in LDS; deeper entries spill to scratch
 
 struct HitRec { float t, u, v; int ref; int tri; bool front; };   // ref = reference index, tri = global triangle id
@@ -231,7 +230,7 @@ MIPT_DEV HitRec traverse_wide(NodePtr nodes, RefPtr refs, v3 o, v3 d, uint32_t* 
 MIPT_DEV void cone_basis(v3 dir, v3& right, v3& up) {
     float rx = dir.z, ry = -dir.x;
     float rlen = __builtin_sqrtf(0.f + rx * rx + ry * ry);
-    right = rlen <= 0 ? mk3(0, 0, 1) : mk3(rx, 0, ry) / rlen;
+    right = rlen <= 0 ? mk3(0, 0, 1) : mk3(rx / rlen, 0.f, ry / rlen);      // (0 / rlen is +0 for rlen > 0: no division spent on it)
     up = cross3(right, dir);
 }
 MIPT_DEV v3 rand_dir_inside_cone(Lcg& rng, v3 dir, float size) {
@@ -319,11 +318,11 @@ MIPT_DEV v3 on_miss(const SceneDev& S, v3 d) {
     return du * p1 + (1 - du) * p0;
 }
 
-struct Material { v3 color; float roughness, metallic, opacity, n, emissiveStrength; v3 emissive; };
+struct Material { v3 color; float roughness, metallic, opacity, n, emissiveStrength; v3 emissive; float r0; };
 MIPT_DEV Material load_material(const SceneDev& S, uint32_t mesh) {
     const float4* M = S.mats + (size_t)mesh * 3;
     float4 a = M[0], b = M[1], c = M[2];
-    Material m; m.color = xyz(a); m.roughness = a.w; m.metallic = b.x; m.opacity = b.y; m.n = b.z; m.emissiveStrength = b.w; m.emissive = xyz(c);
+    Material m; m.color = xyz(a); m.roughness = a.w; m.metallic = b.x; m.opacity = b.y; m.n = b.z; m.emissiveStrength = b.w; m.emissive = xyz(c); m.r0 = c.w;
     return m;
 }
 
@@ -350,7 +349,7 @@ MIPT_DEV Bounce shade_hit(const Material& mat, const Surface& sf, v3 d, bool fro
     b.o1 = P + N * 1e-6f; b.d1 = R;
     float n1 = 1.f, n2 = mat.n; n2 += FLT_EPSILON;
     if (!front) { float t = n1; n1 = n2; n2 = t; }
-    float r0 = (n1 - n2) / (n1 + n2); r0 *= r0;
+    const float r0 = mat.r0;      // ((n1 - n2) / (n1 + n2))^2: the same for either order of n1, n2, so computed once per material on the host (api.hip fill_materials)
     float rr = (1 - dot3(-d, mN));
     rr = pow5_mul(rr);
     rr = r0 + (1 - r0) * rr;
@@ -1068,7 +1067,7 @@ __global__ void __launch_bounds__(kBlock) k_dfs(DfsArgs A) {
             v3 R = reflect3(d, mN);
             float n1 = 1.f, n2 = mat.n; n2 += FLT_EPSILON;
             if (!h.front) { float t = n1; n1 = n2; n2 = t; }
-            float r0 = (n1 - n2) / (n1 + n2); r0 *= r0;
+            const float r0 = mat.r0;      // ((n1 - n2) / (n1 + n2))^2: the same for either order of n1, n2, so computed once per material on the host (api.hip fill_materials)
             float rr = (1 - dot3(-d, mN));
             rr = pow5_mul(rr);
             rr = r0 + (1 - r0) * rr;
