@@ -108,7 +108,19 @@ inline MeshArrays ParsePLY(const char* data, size_t len) {
     std::vector<Vertex> verts; std::vector<std::uint32_t> idx;
     std::vector<std::vector<std::uint32_t>> polys;
     bool haveNormals = false;
+    // list length as a count: finite, non-negative, and no longer than the data that is left could hold
+    auto list_count = [&](const PlyProp& pr) -> size_t {
+        const double c = cur.scalar(pr.countType);
+        if (!(c >= 0.0) || c > (double)(cur.end - cur.p)) throw std::runtime_error("PLY: list length out of range");
+        return (size_t)c;
+    };
     for (const PlyElem& e : elems) {
+        // an element count that the remaining bytes cannot hold is refused before anything is allocated or looped over:
+        // a row takes at least the sizes of its scalars (binary) or a digit and a separator per value (ascii)
+        size_t minRow = 0;
+        for (const PlyProp& pr : e.props) minRow += ascii ? 2 : ply_size(pr.list ? pr.countType : pr.type);
+        if (minRow == 0) { if (e.name == "vertex") throw std::runtime_error("PLY: vertex element without x y z"); continue; }
+        if (e.count > (size_t)(cur.end - cur.p) / minRow + 1) throw std::runtime_error("PLY: unexpected end of data (element " + e.name + " claims more rows than the bytes left can hold)");
         if (e.name == "vertex") {
             int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, iu = -1, iv = -1;
             for (size_t k = 0; k < e.props.size(); k++) {
@@ -125,7 +137,7 @@ inline MeshArrays ParsePLY(const char* data, size_t len) {
             for (size_t i = 0; i < e.count; i++) {
                 for (size_t k = 0; k < e.props.size(); k++) {
                     const PlyProp& pr = e.props[k];
-                    if (pr.list) { size_t c = (size_t)cur.scalar(pr.countType); for (size_t j = 0; j < c; j++) cur.scalar(pr.type); val[k] = 0; }
+                    if (pr.list) { const size_t c = list_count(pr); for (size_t j = 0; j < c; j++) cur.scalar(pr.type); val[k] = 0; }
                     else val[k] = cur.scalar(pr.type);
                 }
                 Vertex& vx = verts[i];
@@ -138,7 +150,7 @@ inline MeshArrays ParsePLY(const char* data, size_t len) {
             for (size_t i = 0; i < e.count; i++) {
                 for (const PlyProp& pr : e.props) {
                     if (!pr.list) { cur.scalar(pr.type); continue; }
-                    const size_t c = (size_t)cur.scalar(pr.countType);
+                    const size_t c = list_count(pr);
                     const bool isIdx = face && (pr.name == "vertex_indices" || pr.name == "vertex_index");
                     std::vector<std::uint32_t> poly;
                     for (size_t j = 0; j < c; j++) {

@@ -207,7 +207,7 @@ struct BvhCacheHeader {
 };
 // Bump kBvhBuilderVersion with any change to the builders, the 4-wide collapse or the quantiser: a cache file written by
 // an earlier build must not be accepted (load_bvh_cache re-validates structure, not that boxes enclose their triangles).
-constexpr uint64_t kBvhBuilderVersion = 4;
+constexpr uint64_t kBvhBuilderVersion = 5;
 uint64_t bvh_cache_key(const std::vector<TriPos>& tris, const BvhParams& bp) {
     uint64_t h = 0xcbf29ce484222325ull;
     auto mix = [&](uint64_t w) { h = (h ^ w) * 0x100000001b3ull; h ^= h >> 29; };

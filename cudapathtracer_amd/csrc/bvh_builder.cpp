@@ -40,6 +40,7 @@ namespace {
 constexpr float kInf = std::numeric_limits<float>::infinity();
 constexpr int kSpatialBins = 32;
 constexpr int kMaxSpatialDepth = 48;
+constexpr int64_t kDupSlack = 64;          // spatial splits may create at most (triangles + kDupSlack) duplicate references
 constexpr uint32_t kBfsLevelsWide = 0, kBfsLevelsBvh2 = 0;     // breadth-first head of the node array (reorder_nodes)
 
 struct Box {
@@ -64,7 +65,7 @@ uint64_t bvh_build_constants_hash() {
     BvhParams d;
     uint32_t nc, ml = d.minLeafSize; memcpy(&nc, &d.nodeCost, 4);
     uint64_t h = 0x9E3779B97F4A7C15ull;
-    for (uint64_t w : { (uint64_t)kSpatialBins, (uint64_t)kMaxSpatialDepth, (uint64_t)kMaxBvhDepth, (uint64_t)kMaxWideStack,
+    for (uint64_t w : { (uint64_t)kSpatialBins, (uint64_t)kDupSlack, (uint64_t)kMaxSpatialDepth, (uint64_t)kMaxBvhDepth, (uint64_t)kMaxWideStack,
                         (uint64_t)kLdsSceneFloat4, (uint64_t)nc, (uint64_t)ml }) { h ^= w; h *= 0x100000001b3ull; h ^= h >> 31; }
     return h;
 }
@@ -104,12 +105,12 @@ public:
 
     // a subtree of a parent Builder: `refs` are its references, the result (root reference, local indices) is
     // returned and the nodes / references land in this Builder's own output
-    uint32_t run_subtree(std::vector<Ref>&& refs, const Spec& s, int level, float minOv) {
+    uint32_t run_subtree(std::vector<Ref>&& refs, const Spec& s, int level, float minOv, int64_t budget) {
         stk = std::move(refs);
         minOverlap = minOv;
         rightB.resize(std::max<size_t>(stk.size(), kSpatialBins));
         O.nodes.clear(); O.refTri.clear(); O.maxDepth = 0;
-        return build(s, level);
+        return build(s, level, budget);
     }
 
     std::string run() {
@@ -134,7 +135,9 @@ public:
             set_child(self, 0, l0, e);
             set_child(self, 1, make_leaf_ref((uint32_t)O.refTri.size(), 0), e);
         } else {
-            uint32_t r = P.builder == 1 ? build_median(root, 0, 32) : build(root, 0);
+            // spatial splits may at most double the references (plus a little for tiny scenes); the allowance is handed down
+            // the tree in proportion to the references on either side, so it does not depend on the thread count
+            uint32_t r = P.builder == 1 ? build_median(root, 0, 32) : build(root, 0, (int64_t)nt + kDupSlack);
             if (r & kLeafFlag) {
                 // SAH preferred a single leaf: wrap it (root must be inner)
                 uint32_t self = new_node();
@@ -213,7 +216,10 @@ private:
     struct ObjSplit { float sah = std::numeric_limits<float>::max(); int dim = 0; int nLeft = 0; Box lb, rb; };
     struct SpaSplit { float sah = std::numeric_limits<float>::max(); int dim = 0; float pos = 0.f; };
 
-    uint32_t build(const Spec& s, int level) {
+    // `budget` = how many duplicate references spatial splits may still create below this node.  Without it a pile of
+    // coincident triangles is split again and again down to kMaxSpatialDepth: 300 identical triangles became 56 100
+    // references and 29 451 nodes (the reference's SplitBVHBuilder has no such limit; Embree's has).
+    uint32_t build(const Spec& s, int level, int64_t budget) {
         if (s.n <= (int)P.minLeafSize) return emit_leaf(s);
         // depth budget: finish with balanced splits when SAH splitting could overrun the device stack
         if (level + ceil_log2((uint32_t)s.n) + 2 >= (int)kMaxBvhDepth) return build_median(s, level, (int)kMaxBvhDepth - level - 1);
@@ -231,8 +237,11 @@ private:
         if (best == leafSAH && s.n <= (int)P.maxLeafSize) return emit_leaf(s);
 
         Spec L, R;
-        if (best == ss.sah) do_spatial_split(L, R, s, ss);
+        if (best == ss.sah) do_spatial_split(L, R, s, ss, budget);      // duplicates at most `budget` straddlers
         if (!L.n || !R.n) do_object_split(L, R, s, os);
+        // what is left of the allowance goes to the children in proportion to their references
+        const int64_t left = std::max<int64_t>(0, budget - ((int64_t)L.n + R.n - s.n));
+        const int64_t budgetL = (L.n + R.n) > 0 ? left * L.n / ((int64_t)L.n + R.n) : 0, budgetR = left - budgetL;
 
         uint32_t self = new_node();
         O.maxDepth = std::max<uint32_t>(O.maxDepth, (uint32_t)level);
@@ -244,19 +253,19 @@ private:
             BvhOut co;
             Builder child(T, P, co, TB);
             uint32_t cr = 0;
-            auto job = [&] { cr = child.run_subtree(std::move(rrefs), R, level + 1, minOverlap); };
+            auto job = [&] { cr = child.run_subtree(std::move(rrefs), R, level + 1, minOverlap, budgetR); };
             if (TB->take()) {
                 auto f = std::async(std::launch::async, [&] { job(); TB->give(); });
-                lr = build(L, level + 1);
+                lr = build(L, level + 1, budgetL);
                 f.get();
             } else {
-                lr = build(L, level + 1);
+                lr = build(L, level + 1, budgetL);
                 job();
             }
             rr = splice(co, cr);
         } else {
-            rr = build(R, level + 1);   // right references are on top of the stack
-            lr = build(L, level + 1);
+            rr = build(R, level + 1, budgetR);   // right references are on top of the stack
+            lr = build(L, level + 1, budgetL);
         }
         set_child(self, 0, lr, L.b); set_child(self, 1, rr, R.b);
         return self;
@@ -366,7 +375,7 @@ private:
     }
     static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-    void do_spatial_split(Spec& L, Spec& R, const Spec& s, const SpaSplit& sp) {
+    void do_spatial_split(Spec& L, Spec& R, const Spec& s, const SpaSplit& sp, int64_t maxDup) {
         // tail layout while working: [left | undecided | right]
         int ls = (int)stk.size() - s.n, le = ls, rs = (int)stk.size();
         L.b = Box(); R.b = Box();
@@ -385,10 +394,11 @@ private:
             float unsplitL = lub.area() * lbc + R.b.area() * rac;
             float unsplitR = L.b.area() * lac + rub.area() * rbc;
             float dup = ldb.area() * lbc + rdb.area() * rbc;
+            if (maxDup <= 0) dup = std::numeric_limits<float>::infinity();     // allowance used up: this straddler goes whole to one side
             float m = std::min(std::min(unsplitL, unsplitR), dup);
             if (m == unsplitL) { L.b = lub; le++; }
             else if (m == unsplitR) { R.b = rub; std::swap(stk[le], stk[--rs]); }
-            else { L.b = ldb; R.b = rdb; stk[le++] = lr; stk.push_back(rr); }
+            else { L.b = ldb; R.b = rdb; stk[le++] = lr; stk.push_back(rr); maxDup--; }
         }
         L.n = le - ls; R.n = (int)stk.size() - rs;
     }
