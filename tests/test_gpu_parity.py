@@ -81,6 +81,52 @@ def test_closest_hit_bit_exact(tracer, ptlib, oracle, builder, scene, width):
     assert len(tracer.trace_rays(sc, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))) == 0
 
 
+@pytest.mark.parametrize("width", [2, 4], ids=["bvh2", "q4"])
+def test_coincident_and_degenerate_triangles(tracer, ptlib, oracle, width):
+    """awkward geometry: a pile of identical triangles (exact t ties: the lowest triangle id wins, on every layout and on
+    the brute-force oracle alike), zero-area triangles (|det| < eps: never hit), and a soup around them"""
+    from conftest import triangle_soup
+    v, i = triangle_soup(400, 9)
+    pile = np.tile(v[:3], 60)                                  # 60 copies of the soup's first triangle
+    degen = np.tile(v[3:4], 90)                                # 30 triangles collapsed to one point
+    line = v[6:9].copy(); line["position"][2] = 0.5 * (line["position"][0] + line["position"][1])     # collinear corners
+    verts = np.concatenate([v, pile, degen, line])
+    idx = np.concatenate([i, len(v) + np.arange(len(pile) + len(degen) + 3, dtype=np.uint32)])
+    data = ptlib.SceneData([(verts, idx, ptlib.make_material())], soup_scene(1, 1).sky)
+    sc = ptlib.Scene(tracer, data, node_width=width)
+    o = oracle.Scene(data)
+    o.set_flat_bvh(*sc.flat())
+    assert o.check_flat_bvh() == (0, "")
+    og, dg = random_rays(200000, 23)
+    # rays aimed at the pile, so that the ties are actually exercised
+    c = verts["position"][len(v):len(v) + 3].mean(axis=0)
+    aim = c[None, :] + np.random.default_rng(5).normal(scale=0.05, size=(50000, 3)).astype(np.float32) - og[:50000]
+    dg[:50000] = aim / np.linalg.norm(aim, axis=1, keepdims=True)
+    g = tracer.trace_rays(sc, og, dg)
+    f, _ = o.trace_rays(oracle.ISECT_FLAT, og, dg, nthreads=16)
+    b, _ = o.trace_rays(oracle.ISECT_BRUTE, og, dg, nthreads=16)
+    assert hits_equal(g, f) == 0
+    assert np.array_equal(g["tri"], b["tri"]) and np.array_equal(g["t"].view(np.uint32), b["t"].view(np.uint32))
+    first_pile = len(i) // 3
+    on_pile = (g["tri"] >= first_pile) & (g["tri"] < first_pile + 60)
+    assert on_pile.sum() == 0 and (g["tri"] == 0).sum() > 1000          # the pile's copies tie with triangle 0 and lose to it
+    assert (g["tri"] >= first_pile + 60).sum() == 0                       # nothing ever hits a zero-area triangle
+    # and the integrator renders it like the oracle does (ray trees per pixel)
+    W, H = 96, 64
+    s = ptlib.make_settings(ptlib.make_camera((-6.0, 0.5, 0.3), 0.0, 1.5, 1.0), W, H, 4)
+    acc, ldr = dev_buffers(tracer, W, H)
+    tracer.set_option("count_pixel_rays", 1)
+    try:
+        tracer.trace(sc, s, acc, ldr)
+        rgb, rays = tracer.last_sample(W * H, rays=True)
+        ref = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, 1, acc=np.zeros((H, W, 4), np.float32), nthreads=16)
+        assert np.array_equal(rays.reshape(H, W), ref["rays"]) and rays.sum() > 2 * W * H
+        assert rel_err(rgb.reshape(H, W, 3), ref["sample"]).max() < RTOL
+    finally:
+        tracer.set_option("count_pixel_rays", 0)
+        tracer.free(acc), tracer.free(ldr)
+
+
 @pytest.mark.parametrize("name", ["cornell", "default"])
 def test_golden_rays(tracer, ptlib, name):
     # committed fixture: brute-force closest hits from the oracle; the BVH path must reproduce primitive id and t
