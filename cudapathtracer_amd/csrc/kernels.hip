@@ -19,6 +19,7 @@
 namespace mipt {
 
 constexpr int kBlock = 256;
+constexpr int kStackStride = kBlock;   // dword stride between a lane's LDS stack entries (k_wavestack shadows it with its own block size)
 constexpr uint32_t kLeaf = 0x80000000u;
 constexpr uint32_t kTerm = 0xFFFFFFFFu;
 constexpr int kStackCap = 64;      // == kMaxBvhDepth of the builder
@@ -86,17 +87,17 @@ MIPT_DEV bool mt_test(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, int id, int b
 // register and the two halves are reached through separate branches: folding them into one struct/pointer select
 // puts the pointer itself in scratch and turns every pop into a flat load behind a scratch load.
 #define MIPT_STACK_PUSH(lds_, deep_, sp_, x_)                                              \
-    do { if ((sp_) < kLdsStack) (lds_)[(sp_) * kBlock] = (x_); else (deep_)[(sp_) - kLdsStack] = (x_); (sp_)++; } while (0)
+    do { if ((sp_) < kLdsStack) (lds_)[(sp_) * kStackStride] = (x_); else (deep_)[(sp_) - kLdsStack] = (x_); (sp_)++; } while (0)
 #define MIPT_STACK_POP(lds_, deep_, sp_, out_)                                             \
     do { (sp_)--;                                                                            \
-         if ((sp_) < kLdsStack) { (out_) = (lds_)[(sp_) * kBlock]; asm volatile("" : "+v"(out_)); }      /* keep ds_read ... */ \
+         if ((sp_) < kLdsStack) { (out_) = (lds_)[(sp_) * kStackStride]; asm volatile("" : "+v"(out_)); }      /* keep ds_read ... */ \
          else { (out_) = (deep_)[(sp_) - kLdsStack]; asm volatile("" : "+v"(out_)); }                    /* ... and scratch_load apart */ \
     } while (0)
 
 // LDS-resident scenes are only traversed this way when the builder's stack bound fits the LDS part (the host checks
 // SceneDev::stackNeed <= kLdsStack), so their pushes and pops need no scratch branch at all.
-#define MIPT_STACK_PUSH_L(lds_, sp_, x_) do { (lds_)[(sp_) * kBlock] = (x_); (sp_)++; } while (0)
-#define MIPT_STACK_POP_L(lds_, sp_, out_) do { (sp_)--; (out_) = (lds_)[(sp_) * kBlock]; } while (0)
+#define MIPT_STACK_PUSH_L(lds_, sp_, x_) do { (lds_)[(sp_) * kStackStride] = (x_); (sp_)++; } while (0)
+#define MIPT_STACK_POP_L(lds_, sp_, out_) do { (sp_)--; (out_) = (lds_)[(sp_) * kStackStride]; } while (0)
 
 // Closest hit (TraceRay, CUDATracerProg.cu:543-794) on the flat scene BVH.  Near child first, far child pushed;
 // leaves are tested when they become current; hitT shrinks as hits are found and culls later box tests.
@@ -607,10 +608,17 @@ MIPT_DEV uint32_t wave_sum_u32(uint32_t v) { for (int s = 32; s > 0; s >>= 1) v 
 #endif
 
 #define MIPT_BALLOT(x) __builtin_amdgcn_ballot_w64(x)      // wave64 mask of a per-lane predicate
+// Threads per persistent block.  A block's CU slot is only handed to the next frame's blocks when all its waves have ended, so
+// one-wave blocks let the next frame move in wave by wave: Default +3.9 %, grid +2.1 % (profiles/r2/exp_blocksize.log; 128
+// threads: +0.5 %).  A one-wave block takes a sixteenth of the CU's LDS (3 KiB stack + 7 KiB shade queue).  LDS-resident
+// scenes keep four waves per block: they share the block's copy of the scene.
+template <bool LDS_SCENE> struct WaveStackBlock { static constexpr int value = LDS_SCENE ? 256 : 64; };
+// 4 waves per SIMD at the 128-VGPR cap (4-5 spills outside the hot loops).  Three with the ~145 VGPRs the compiler would
+// like (no spills) run 0.85x; five at 96 VGPRs and 32 KiB of LDS per 256 threads spill 35-40 registers, 0.6-0.7x.
 template <bool LDS_SCENE, bool WIDE, bool NEE, bool PBS = false>
-// 4 blocks per CU = 4 waves per SIMD at the 128-VGPR cap (4-5 spills outside the hot loops).  Three blocks with the
-// ~145 VGPRs the compiler would like (no spills) run 0.85x; five at 96 VGPRs and 32 KiB of LDS spill 35-40 registers, 0.6-0.7x.
-__global__ void __launch_bounds__(kBlock, 4) k_wavestack(StackArgs A) {
+__global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavestack(StackArgs A) {       // (hipcc: second argument = minimum waves per SIMD)
+    constexpr int kBlock = WaveStackBlock<LDS_SCENE>::value;       // shadows the file-wide block size inside this kernel
+    constexpr int kStackStride = kBlock;
     constexpr int kSqCap = SqCap<LDS_SCENE>::value;
     constexpr bool kShortRcp = true;       // 3-instruction reciprocals for the rays this kernel generates itself (ray_pre, mt_test): +2-3 %
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
@@ -995,23 +1003,23 @@ bool wavestack_scene_in_lds(const SceneDev& S) {
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
     const bool lds = wavestack_scene_in_lds(a.S);
     if (a.nee == 3u) {      // estimator 3: the lobes of 2 with the light sampling of 1
-        if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, true, true>), dim3(blocks * 4), dim3(64), 0, s, a);
         else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((k_wavestack<false, false, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_wavestack<false, false, true, true>), dim3(blocks * 4), dim3(64), 0, s, a);
     }
     else if (a.nee == 2u) {      // estimator 2: VNDF specular + cosine diffuse, no occlusion rays
-        if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false, true>), dim3(blocks * 4), dim3(64), 0, s, a);
         else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((k_wavestack<false, false, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_wavestack<false, false, false, true>), dim3(blocks * 4), dim3(64), 0, s, a);
     }
     else if (a.nee) {
-        if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, true>), dim3(blocks * 4), dim3(64), 0, s, a);
         else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((k_wavestack<false, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_wavestack<false, false, true>), dim3(blocks * 4), dim3(64), 0, s, a);
     }
-    else if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false>), dim3(blocks), dim3(kBlock), 0, s, a);
+    else if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false>), dim3(blocks * 4), dim3(64), 0, s, a);
     else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, false>), dim3(blocks), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((k_wavestack<false, false, false>), dim3(blocks), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((k_wavestack<false, false, false>), dim3(blocks * 4), dim3(64), 0, s, a);
 }
 
 // =================================================================================================================
@@ -1136,9 +1144,12 @@ MIPT_DEV unsigned char tonemap1(float x) {
 // zeroAfter: the sample slot is cleared as soon as it has been read, so the next frame that uses it needs no clear of
 // its own (one 16 B/pixel fill kernel per frame less)
 // zeroCounters: the 64 pixel counters of the frame being folded, cleared for the next frame that uses the block
-__global__ void __launch_bounds__(kBlock) k_accumulate(float4* sample, float4* acc, uchar4* ldr, float weight, int sumMode, int zeroAfter,
+// One-wave blocks: the fold runs next to the persistent integrator, whose slots free up one wave at a time; a 256-thread
+// block would wait until four of them are free on one CU at once (grid: 8.64 -> 8.87 ms per frame when it did).
+constexpr int kFoldBlock = 64;
+__global__ void __launch_bounds__(kFoldBlock) k_accumulate(float4* sample, float4* acc, uchar4* ldr, float weight, int sumMode, int zeroAfter,
                                                         uint32_t* zeroCounters, Band band, uint32_t pix0, uint32_t npix) {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t i = blockIdx.x * kFoldBlock + threadIdx.x;
     if (zeroCounters && i < 64u) zeroCounters[i] = 0u;
     if (i >= npix) return;
     uint32_t p = pix0 + i;
@@ -1153,18 +1164,18 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(float4* sample, float4* a
 }
 void launch_accumulate(float* sample, float* acc, unsigned char* ldr, float weight, int sumMode, int zeroAfter, uint32_t* zeroCounters, Band band, uint32_t pix0, uint32_t npix, hipStream_t s) {
     if (!npix) return;
-    hipLaunchKernelGGL(k_accumulate, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (float4*)sample, (float4*)acc, (uchar4*)ldr,
+    hipLaunchKernelGGL(k_accumulate, dim3((npix + kFoldBlock - 1) / kFoldBlock), dim3(kFoldBlock), 0, s, (float4*)sample, (float4*)acc, (uchar4*)ldr,
                        weight, sumMode, zeroAfter, zeroCounters, band, pix0, npix);
 }
-__global__ void __launch_bounds__(kBlock) k_tonemap(const float4* acc, float scale, uint32_t npix, uchar4* ldr) {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+__global__ void __launch_bounds__(kFoldBlock) k_tonemap(const float4* acc, float scale, uint32_t npix, uchar4* ldr) {
+    uint32_t i = blockIdx.x * kFoldBlock + threadIdx.x;
     if (i >= npix) return;
     float4 a = acc[i];
     ldr[i] = make_uchar4(tonemap1(a.x * scale), tonemap1(a.y * scale), tonemap1(a.z * scale), 255);
 }
 void launch_tonemap(const float* acc, float scale, uint32_t npix, unsigned char* ldr, hipStream_t s) {
     if (!npix) return;
-    hipLaunchKernelGGL(k_tonemap, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const float4*)acc, scale, npix, (uchar4*)ldr);
+    hipLaunchKernelGGL(k_tonemap, dim3((npix + kFoldBlock - 1) / kFoldBlock), dim3(kFoldBlock), 0, s, (const float4*)acc, scale, npix, (uchar4*)ldr);
 }
 
 // =================================================================================================================
