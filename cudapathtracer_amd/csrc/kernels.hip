@@ -518,9 +518,12 @@ void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s) {
 // 256 * maxDepth + 256 entries per wave and the kernel raises an error flag instead of writing past it.
 // =================================================================================================================
 // shade-queue entries per wave (a terminated ray that finds it full parks one round later); sized so that a
-// 256-thread block uses exactly a quarter of the CU's 160 KiB: 4 x cap x 64 B + 12 KiB traversal stacks (+ 4 KiB scene); 12 stack entries / cap 112 measured better than 8 / 128 and 16 / 96
+// wave uses exactly a sixteenth of the CU's 160 KiB: cap x 64 B + 3 KiB traversal stack (LDS scenes: 2 KiB + a share of the 4 KiB scene); 12 stack entries / cap 112 measured better than 8 / 128 and 16 / 96
 MIPT_DEV uint32_t band_pixel(const Band& b, uint32_t local) { return ((local / b.pixels) * b.stride + b.first) * b.pixels + local % b.pixels; }
-template <bool LDS_SCENE> struct SqCap { static constexpr int value = LDS_SCENE ? 96 : 112; };
+// LDS-resident scenes are tiny trees: 8 LDS stack entries cover them (the host checks stackNeed), which leaves their
+// blocks the same 112-entry queue next to the 4 KiB scene window (96 entries with a 12-entry stack: 1 % slower on Cornell)
+constexpr int kLdsSceneStack = 8;
+template <bool LDS_SCENE> struct SqCap { static constexpr int value = 112; };
 constexpr int kSqWords = 16;         // dwords per entry, SoA by dword: conflict-free LDS access
 
 // wave-stack records: plain cached accesses.  The stack is LIFO, so what was pushed last is popped next and L2 is exactly
@@ -621,7 +624,7 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
     constexpr int kStackStride = kBlock;
     constexpr int kSqCap = SqCap<LDS_SCENE>::value;
     constexpr bool kShortRcp = true;       // 3-instruction reciprocals for the rays this kernel generates itself (ray_pre, mt_test): +2-3 %
-    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    __shared__ uint32_t ldsStack[(LDS_SCENE ? kLdsSceneStack : kLdsStack) * kBlock];
     __shared__ float sqMem[(kBlock / 64) * kSqWords * kSqCap];
     __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneVec : 1];
     if (LDS_SCENE) {
@@ -997,7 +1000,7 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
 }
 
 bool wavestack_scene_in_lds(const SceneDev& S) {
-    return !S.wide && S.nNodes * 4 + S.nRefs * 3 <= kLdsSceneVec && S.stackNeed <= (uint32_t)kLdsStack;
+    return !S.wide && S.nNodes * 4 + S.nRefs * 3 <= kLdsSceneVec && S.stackNeed <= (uint32_t)kLdsSceneStack;
 }
 
 void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
