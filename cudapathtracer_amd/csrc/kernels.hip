@@ -736,20 +736,36 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
             }
             const unsigned long long sm = NEE ? MIPT_BALLOT(wantEnv) : 0ull, em = NEE ? MIPT_BALLOT(wantEmit) : 0ull;
             const uint32_t nEnvRays = (uint32_t)__popcll(sm);
-            const uint32_t total = 2u * n + nEnvRays + (uint32_t)__popcll(em);
+            // Hand-off: a lane without a ray keeps the second child of the record it has just shaded, so that child makes no
+            // trip through the wave stack (throughput unchanged; HBM traffic per Cornell frame 8.6 -> 4.9 GB, most of it
+            // write-backs of stack lines that were dead by the time they were evicted: profiles/r2/exp_handoff.log).
+            // Not for the light-sampling variants, which are short of registers as it is.
+            const bool takeOwn = !NEE && has && !active;
+            const unsigned long long tk = NEE ? 0ull : MIPT_BALLOT(takeOwn);
+            const uint32_t total = 2u * n + nEnvRays + (uint32_t)__popcll(em) - (uint32_t)__popcll(tk);
             if (sp + total > A.cap) {
                 if (lane == 0) atomicOr(A.stats + 39, 1ull);       // overflow: reported by the host, never written past
             } else {
                 if (has) {
-                    const uint32_t w = sp + 2u * lane;
+                    const uint32_t w = sp + 2u * lane - (uint32_t)__popcll(tk & below);
                     uint32_t flags2 = 0;
                     if (NEE && opaque) flags2 = (A.S.envCdf ? kNoEnvBit : 0u) | (A.S.nEmit ? kNoEmitBit : 0u);
                     stack_store(&qa[w], make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x));
                     stack_store(&qb[w], make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y));
                     stack_store(&qc[w], make_float4(b.f1.z, __uint_as_float(spix), __uint_as_float(snode * 2u), __uint_as_float(ss0)));
-                    stack_store(&qa[w + 1], make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x));
-                    stack_store(&qb[w + 1], make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y));
-                    stack_store(&qc[w + 1], make_float4(b.f2.z, __uint_as_float(spix | flags2), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0)));
+                    if (takeOwn) {
+                        o = b.o2; d = b.d2; beta = b.f2; pix = spix; node = snode * 2u + 1u; s0 = ss0;
+                        r = ray_pre<kShortRcp>(o, d);
+                        h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
+                        tsp = 0;
+                        if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, kTerm); else MIPT_STACK_PUSH(lstk, deep, tsp, kTerm);
+                        cur = 0; active = true; traced++;
+                        if (A.pixelRays) atomicAdd(A.pixelRays + pix, 1u);
+                    } else {
+                        stack_store(&qa[w + 1], make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x));
+                        stack_store(&qb[w + 1], make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y));
+                        stack_store(&qc[w + 1], make_float4(b.f2.z, __uint_as_float(spix | flags2), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0)));
+                    }
                 }
                 // occlusion rays: the record's node word carries tmax (+inf towards the environment)
                 if (NEE && wantEnv) {
