@@ -1,8 +1,9 @@
 /*
  * oracle.cpp -- scalar CPU restatement of the reference path tracer.
  *
- * TEST INFRASTRUCTURE ONLY (see oracle.h).  "parity unpinned by the reference": the reference holds no golden
- * vectors for this path and cannot be built here; this file restates its algorithm and every function cites the
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  Parity is pinned by images only: the reference holds no golden vectors for
+ * this path and cannot be built here, its two README screenshots are what the oracle is checked against (oracle.h);
+ * below their resolution parity is unpinned.  This file restates the reference's algorithm and every function cites the
  * reference lines it follows.  Paths are relative to /root/reference.
  *
  * Arithmetic contract (shared, by specification, with the HIP kernels): IEEE fp32, evaluated exactly as the

@@ -7,12 +7,17 @@
  * product library (cudapathtracer_amd/libmipt.so) never includes, links or
  * calls anything declared here.
  *
- * PARITY STATUS: "parity unpinned by the reference".  The reference
+ * PARITY STATUS: pinned coarsely, by images only.  The reference
  * (0x5b25/CUDAPathTracer) ships no tests, golden vectors or fixtures for this
  * path and cannot be compiled in this image
- * (MSVC + CUDA 10.2 only).  The oracle is therefore a scalar restatement of
- * CUDATracer/CUDATracerProg/CUDATracerProg.cu, pinned only by the known-answer
- * RNG vectors in BASELINE.md section 3 and by analytic/brute-force self checks.
+ * (MSVC + CUDA 10.2 only).  The oracle is a scalar restatement of
+ * CUDATracer/CUDATracerProg/CUDATracerProg.cu.  What the reference does hold
+ * are its two README screenshots; the oracle is checked against both
+ * (tests/test_oracle_render.py: Cornell box block by block in brightness,
+ * colour and structure; Default scene in geometry and hues through a fitted
+ * camera).  No bit-level vector of the reference exists: below the resolution
+ * of those images parity is unpinned, and the oracle rests on the known-answer
+ * RNG vectors in BASELINE.md section 3 and analytic / brute-force self checks.
  *
  * All structs mirror the reference PODs byte-for-byte
  * (CUDATracer/Types.hpp:20-39,214-231; CUDATracer/CUDATracer.hpp:11-17).

@@ -18,7 +18,24 @@ SRC = "/root/reference/imgs/tracer02_cornellbox.png"
 CLIENT = (31, 511, 3, 803)          # y0, y1, x0, x1 of the 480 x 800 client area inside the 512 x 806 screenshot
 
 
+def default_scene():
+    """The other screenshot, imgs/tracer01_default.png (README.md:5): the Default scene under the author's HDRI, from a camera the
+    author had moved (the app's start camera looks along +x at eye height, this one looks down on the table).  801 x 514 with
+    chrome; client area [32:512, 1:801], box-downsampled 4x4 -> 120 x 200 RGB bytes.  Neither the HDRI nor the camera is in the
+    reference, so this fixture pins geometry and material hues only (tests/golden/fit_default_camera.py recovers the camera)."""
+    a = np.asarray(Image.open("/root/reference/imgs/tracer01_default.png").convert("RGB")).astype(np.float64)
+    assert a.shape == (514, 801, 3), a.shape
+    border = np.array([24, 131, 215])
+    assert (a[32:512, 0] == border).all(-1).mean() > 0.9 and (a[512, 1:800] == border).all(-1).mean() > 0.9
+    c = a[32:512, 1:801]
+    small = np.rint(c.reshape(120, 4, 200, 4, 3).mean((1, 3))).astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "ref_default_screenshot.npz"), ldr_small=small, client=np.array((32, 512, 1, 801)),
+                        source=np.array("0x5b25/CUDAPathTracer imgs/tracer01_default.png (README.md:5), client area 800x480 box-downsampled 4x4"))
+    print("wrote ref_default_screenshot.npz", small.shape)
+
+
 def main():
+    default_scene()
     a = np.asarray(Image.open(SRC).convert("RGB")).astype(np.float64)
     assert a.shape == (512, 806, 3), a.shape
     y0, y1, x0, x1 = CLIENT
