@@ -208,6 +208,31 @@ def test_gpu_matches_the_reference_screenshot(tracer, ptlib):
     check_screenshot_structure(m)
 
 
+def test_gpu_default_scene_matches_the_reference_screenshot(tracer, ptlib):
+    """The product against the reference's other screenshot (Default scene; camera fitted to its outlines, see
+    test_oracle_render.test_default_scene_matches_the_reference_screenshot): the closest hits of libmipt's own rays through
+    the 200 x 120 pixel centres must cover, per object, the pixels the screenshot's colours assign to it."""
+    import importlib.util
+    import json
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("fit_default_camera", os.path.join(gold, "fit_default_camera.py"))
+    F = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(F)
+    cam = json.load(open(os.path.join(gold, "ref_default_camera.json")))
+    data = ptlib.builtin_scene(1, None)
+    tri_mesh = F.triangle_meshes(data)
+    _, masks = F.classes_of_screenshot()
+    O, D = F.primary_rays(np.array([*cam["pos"], cam["azimuth"], cam["zenith"]]))
+    for width in (2, 4):
+        sc = ptlib.Scene(tracer, data, node_width=width)
+        t = tracer.trace_rays(sc, O, D)["tri"].reshape(F.H, F.W)
+        mm = np.where(t >= 0, tri_mesh[np.maximum(t, 0)], -1)
+        ov = F.overlaps(mm, masks)
+        assert ov[F.TEAL] > 0.97 and ov[F.GOLD] > 0.85 and ov[F.GREEN] > 0.7 and ov[F.GROUND] > 0.9, ov
+        assert (mm == F.GLASS).sum() > 600 and ((mm == F.GLASS) & (masks[F.TEAL] | masks[F.GOLD] | masks[F.GREEN])).sum() == 0
+
+
 def test_env_map_lookup(tracer, ptlib, oracle):
     # an open scene: every path ends in an env-map texel (OnMiss, CUDATracerProg.cu:809-844), incl. poles and seam
     env = ptlib.synthetic_sky(128, 64, 7)
