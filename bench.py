@@ -2,6 +2,7 @@
 """Benchmark of the hot path: PathTracer::Trace (one sample per pixel per step) on N MI355X.
 
   python bench.py --gpus 1 --steps 8 --warmup 2
+  python bench.py --gpus N ...            (no launcher: bench.py starts the N ranks itself, see spawn_ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one frame (1 spp) of the workload per GPU.  The headline workload (`metric`, `value`, `ms_per_step`, `roofline`,
@@ -12,17 +13,19 @@ attaches them under `workloads` in the ONE JSON line.  `--workload cornell|defau
 
 Timed region: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks.
 Because K frames of a cache-resident scene take ~0.1 s, that K-step measurement is repeated until the repeats add up to
-`--min-seconds` (1 s) and the MEDIAN repeat is reported (`repeats`, `timed_region_s` say how many and how long).
+`--min-seconds` (5 s: long enough for a 5 s utilisation sampler to see the device busy) and the MEDIAN repeat is reported (`repeats`, `timed_region_s` say how many and how long).
 With N > 1 the scene is replicated, rank r renders frame indices r, r+N, ... into a private sum buffer (weak scaling:
 one frame per GPU per step) and ONE RCCL reduce of the accumulation buffers closes every timed repeat.
 
-Roofline (per workload, dominant kernel k_wavestack): a scene whose BVH + triangles fit the 32 MiB of L2 is bound by
-VALU issue, not HBM -- `bound: "valu"`, achieved = ALGORITHMIC lane-operations per launch (per node visit,
-per triangle test, per shade, counts from the CPU oracle on the same flat BVH) / the launch's HIP-event duration, peak =
-the guide's fp32 vector rate.  The grid keeps `bound: "hbm"` with SURVEY 8d's algorithmic bytes per ray -- as long as
-those bytes per second stay below the HBM peak; beyond it the caches are demonstrably serving part of them, the HBM roof
-does not bind and the headline falls back to the VALU fraction.  The headline fraction is therefore at most 1 and both
-sub-objects (`valu`, `hbm`) are always attached.
+Roofline (per workload, dominant kernel k_wavestack).  Both bounds are always computed and attached: `valu` = ALGORITHMIC
+lane-operations per launch (per node visit, per triangle test, per shade, counts from the CPU oracle on the same
+flat BVH) / the launch's HIP-event duration against the guide's fp32 vector rate; `hbm` = SURVEY 8d's algorithmic bytes per
+ray against 8 TB/s, with the MEASURED traffic (`traffic_gb_per_launch`, `traffic_frac`: rocprofv3 PMC passes, 2 x FETCH_SIZE
++ WRITE_SIZE) beside it.  Which of the two is the headline is read from counters, not from the scene's size: `valu` when
+the PMC passes of that workload show the un-packed VALU issue slots >= 0.8 busy (`bound_from` spells out the figures and
+the file they come from); a configuration without counters falls back to working set vs L2.
+`trace_loop` is the same workload driven through the reference's own call sequence (Trace + blocking bitmap read-back per
+frame): the per-frame figure an interactive caller sees, PCIe included, beside the batched, pipelined `value`.
 """
 import argparse
 import hashlib
@@ -62,7 +65,10 @@ def parse():
     p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--workload", default="all", choices=["all", "cornell", "default", "grid"],
                    help="all (default): cornell is the headline, default and grid are attached under `workloads`")
-    p.add_argument("--min-seconds", type=float, default=1.0, help="the K-step measurement is repeated until the repeats add up to this")
+    p.add_argument("--min-seconds", type=float, default=5.0, help="the K-step measurement is repeated until the repeats add up to this")
+    p.add_argument("--share-gpus", action="store_true", help="rehearsal: allow more ranks than visible GPUs (ranks are placed round-robin; needs --backend gloo, RCCL refuses two ranks on one GPU)")
+    p.add_argument("--rehearse-launch", action="store_true", help="CPU rehearsal of the N-rank control flow only (launch, rendezvous, frame partition, closing reduce, rank-0 line): traces NOTHING, reports value null")
+    p.add_argument("--trace-loop-frames", type=int, default=48, help="frames of the reference's own call sequence (Trace + blocking LDR read-back per frame) timed for `trace_loop`; 0 disables")
     p.add_argument("--width", type=int, default=0, help="0 = 1920 (cornell, default) or 3840 (grid)")
     p.add_argument("--height", type=int, default=0, help="0 = 1080 (cornell, default) or 2160 (grid)")
     p.add_argument("--depth", type=int, default=0, help="0 = 8 for cornell, 12 for default, 4 for grid (BASELINE.json)")
@@ -95,14 +101,14 @@ def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0)
         s = pt.Settings()
         C.memmove(C.addressof(s), C.addressof(settings), C.sizeof(pt.Settings))
         s.maxDepth = depth
-        tot = dict(rays=0, nodes=0, tris=0, hits=0, sec=0.0)
+        tot = dict(rays=0, nodes=0, tris=0, hits=0, anyhit=0, sec=0.0)
         acc = np.zeros((H, W, 4), np.float32)
         for y in rows:      # bands of BAND rows: enough 64-pixel work items per call to keep 16 threads busy
             t0 = time.perf_counter()
             r = o.render(s, orc.ISECT_FLAT, orc.RNG_NODE, orc.MATH_DET, 0, 1, rect=(0, y, W, min(y + BAND, H)), acc=acc, want_ldr=False, nthreads=threads)
             tot["sec"] += time.perf_counter() - t0
             st = r["stats"]
-            tot["rays"] += st.rays; tot["nodes"] += st.node_visits; tot["tris"] += st.tri_tests; tot["hits"] += st.hits
+            tot["rays"] += st.rays; tot["nodes"] += st.node_visits; tot["tris"] += st.tri_tests; tot["hits"] += st.hits; tot["anyhit"] += st.anyhit_rays
         return tot
 
     BAND = 8
@@ -118,7 +124,7 @@ def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0)
         t0 = time.perf_counter()
         r = o.render(s, orc.ISECT_FLAT, orc.RNG_NODE, orc.MATH_DET, 0, n_frames, want_ldr=False, nthreads=threads)
         st = r["stats"]
-        full = dict(rays=st.rays, nodes=st.node_visits, tris=st.tri_tests, hits=st.hits, sec=time.perf_counter() - t0)
+        full = dict(rays=st.rays, nodes=st.node_visits, tris=st.tri_tests, hits=st.hits, anyhit=st.anyhit_rays, sec=time.perf_counter() - t0)
         desc = f"frames 0..{n_frames - 1} of the same workload, whole"
     else:
         n_bands = max(1, n_rows // BAND)
@@ -127,7 +133,7 @@ def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0)
         desc = f"{len(rows)} evenly spaced bands of {BAND} rows of frame 0 of the same workload"
     rays = max(full["rays"], 1)
     return dict(desc=desc, rays=full["rays"], sec=full["sec"], mrays=full["rays"] / full["sec"] / 1e6,
-                n_node=full["nodes"] / rays, n_tri=full["tris"] / rays, miss=1.0 - full["hits"] / rays)
+                n_node=full["nodes"] / rays, n_tri=full["tris"] / rays, miss=1.0 - full["hits"] / rays, anyhit=full["anyhit"] / rays)
 
 
 def dbg(msg):
@@ -145,23 +151,30 @@ def source_sha16():
 
 
 def pmc_for(workload, default_config):
-    """HBM bytes per launch etc. from the committed rocprofv3 --pmc passes of this same command, tagged with where they
-    come from; None when they were measured on other sources or another configuration (never silently stale)."""
+    """(figures, label): HBM bytes per launch etc. from the committed rocprofv3 --pmc passes of this same command, tagged with
+    where they come from.  `figures` is None when they were measured on other sources or another configuration (never
+    silently stale); `label` is the newest committed entry of this workload at its default configuration whatever the
+    sources -- used ONLY to name what binds (valu_busy), with its origin spelled out beside it."""
     if not default_config:
-        return None
-    for rnd in ("r2", "r1"):
+        return None, None
+    label = None
+    for rnd in ("r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         try:
             pj = json.load(open(path))
         except Exception:
             continue
         meta = pj.get("_meta", {})
-        if meta.get("source_sha16") != source_sha16() or workload not in pj:
+        if workload not in pj:
             continue
         e = dict(pj[workload])
-        e["source"] = f"profiles/{rnd}/pmc_traffic.json ({meta.get('collected', 'rocprofv3 --pmc')}; sources {meta.get('source_sha16')})"
-        return e
-    return None
+        same = meta.get("source_sha16") == source_sha16()
+        e["source"] = f"profiles/{rnd}/pmc_traffic.json ({meta.get('collected', 'rocprofv3 --pmc')}; sources {meta.get('source_sha16')}{'' if same else ', NOT the sources of this build'})"
+        if label is None:
+            label = e
+        if same:
+            return e, e
+    return None, label
 
 
 def build_scene(pt, a, name, t, rank, multi, dist):
@@ -192,6 +205,37 @@ def build_scene(pt, a, name, t, rank, multi, dist):
     else:
         sc = pt.Scene(t, data, node_width=a.node_width, tri_cost=a.tri_cost, max_leaf=a.max_leaf)
     return data, settings, sc, W, H, depth
+
+
+def trace_loop(pt, t, sc, settings, W, H, frames):
+    """The reference's own frame loop, call for call (Common/RendererWindow.hpp:100-148): two CUDABuffer work-alikes for the
+    accumulation image and the bitmap, then per frame Trace -> bitmap->cpu_data() (a BLOCKING device-to-host copy of the
+    w*h*4 LDR bytes into the pinned mirror) -> frameID++.  Frames cannot overlap in this sequence, and the copy rides on
+    PCIe: this is what an interactive RendererWindow caller gets per frame.  It is reported beside the batched figure and
+    is never `value` (the boundary of the path hands over device pointers)."""
+    import ctypes as C
+    accb, bitmap = pt.Buffer(t, W * H * 16), pt.Buffer(t, W * H * 4)
+    s = pt.Settings()
+    C.memmove(C.addressof(s), C.addressof(settings), C.sizeof(pt.Settings))
+
+    def frame(i):
+        s.frameID = i
+        t.trace(sc, s, accb.mutable_gpu_data(), bitmap.mutable_gpu_data())
+        return bitmap.cpu_data()
+
+    for i in range(4):
+        frame(i)
+    c0 = t.counters()
+    t0 = time.perf_counter()
+    for i in range(4, 4 + frames):
+        frame(i)
+    dt = time.perf_counter() - t0
+    c1 = t.counters()
+    accb.close(); bitmap.close()
+    return {"ms_per_frame": round(dt / frames * 1e3, 3), "mrays_per_s": round((c1.rays - c0.rays) / dt / 1e6, 1), "frames": frames,
+            "sequence": "per frame: mipt_trace (1 spp, fold + tonemap) then a blocking read-back of the RGBA8 bitmap into pinned host memory, frameID++ "
+                        "(RendererWindow::render, Common/RendererWindow.hpp:128-148); PCIe-inclusive, frames do not overlap",
+            "ldr_bytes_per_frame": W * H * 4}
 
 
 def run_workload(name, a, ctx, cpu_seconds):
@@ -283,7 +327,7 @@ def run_workload(name, a, ctx, cpu_seconds):
             threads = min(os.cpu_count() or 1, 16)
             cpu = oracle_sample(pt, data, (nodes, refs), sc.bvh_width, settings, cpu_seconds if world == 1 else min(cpu_seconds, 3.0), threads, a.estimator)
         default_config = (W, H, depth) == WORKLOADS[name][1:] and (name != "grid" or a.grid_n == 2236) and not a.node_width and not a.tri_cost and not a.max_leaf and not a.estimator and not a.option and a.integrator == 0 and a.pipeline == 1
-        pmc = pmc_for(name, default_config)
+        pmc, pmc_label = pmc_for(name, default_config)
         working_set = nn * 64 + nr * 48
         roof = None
         if cpu is not None and sec_ms > 0 and sec_launches > 0:
@@ -321,11 +365,17 @@ def run_workload(name, a, ctx, cpu_seconds):
                 valu["pmc"] = {k: pmc[k] for k in ("valu_busy", "lane_utilisation", "wait_frac", "l2_hit") if k in pmc}
                 if "executed_lane_ops_per_launch" in pmc:      # what the kernel executes per ray against what the algorithm needs
                     valu["pmc"]["executed_lane_ops_per_ray"] = round(pmc["executed_lane_ops_per_launch"] / rays_launch, 1)
-            # A working set beyond L2 goes to HBM -- unless the caches catch so much re-use that the algorithmic bytes per
-            # second exceed what HBM can deliver: then they demonstrably did not all come from HBM, that roof does not bind
-            # and the line falls back to the VALU bound (both objects stay in the line either way).
-            hbm_binds = working_set > (32 << 20) and hbm["frac"] <= 1.0
-            bound = "hbm" if hbm_binds else "valu"
+            # What binds is read from counters, not from a size threshold: VALU issue when the un-packed issue slots are
+            # >= 0.8 busy (PMC valu_busy of this workload's default configuration), HBM when the measured traffic is the
+            # larger share of its peak.  Without counters for this configuration: a working set inside L2 cannot be HBM
+            # bound; beyond L2 the algorithmic bytes decide as long as they stay below the peak.
+            if pmc_label is not None and "valu_busy" in pmc_label:
+                traffic_frac_label = pmc_label.get("hbm_gb_per_launch", 0.0) / launch_s / HBM_PEAK_GBS
+                bound = "valu" if (pmc_label["valu_busy"] >= 0.8 or pmc_label["valu_busy"] >= traffic_frac_label) else "hbm"
+                bound_from = f"counters: valu_busy {pmc_label['valu_busy']:.3f}, measured HBM traffic {traffic_frac_label:.2f} of peak; {pmc_label['source']}"
+            else:
+                bound = "hbm" if (working_set > (32 << 20) and hbm["frac"] <= 1.0) else "valu"
+                bound_from = "no counters for this configuration: working set against the 32 MiB of L2"
             head = hbm if bound == "hbm" else valu
             roof = {"bound": bound, "achieved": head["achieved"], "peak": head["peak"], "unit": head["unit"], "frac": head["frac"],
                     "traffic": hbm["traffic_gb_per_launch"], "traffic_unit": "GB per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
@@ -337,9 +387,7 @@ def run_workload(name, a, ctx, cpu_seconds):
                     # with (or queues behind) its neighbour; the wall figures divide the timed region by the launches instead
                     "frames_pipelined": bool(a.pipeline and a.integrator == 0), "wall_ms_per_launch": round(wall_s * 1e3, 4),
                     "working_set_mb": round(working_set / 1e6, 2),
-                    "bound_reason": ("BVH + triangles exceed the 32 MiB of L2 (and the 256 MiB Infinity Cache): node / triangle fetches go to HBM" if bound == "hbm" else
-                                     "algorithmic bytes per second exceed the HBM peak: the caches serve the difference, the HBM roof does not bind; VALU issue does" if working_set > (32 << 20) else
-                                     "BVH + triangles fit LDS / L2: algorithmic bytes are served on-chip, VALU issue binds (PMC: valu_busy)"),
+                    "bound_from": bound_from,
                     "valu": valu, "hbm": hbm}
         out = {
             "value": round(total_rays / dt / 1e6, 1), "unit": "Mrays/s", "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -349,13 +397,23 @@ def run_workload(name, a, ctx, cpu_seconds):
                        "triangles": data.triangle_count, "bvh": "sbvh" + ("-q4" if sc.bvh_width == 4 else ""), "rng": "node", "integrator": "wave-stacks" if a.integrator == 0 else "level-queues", "parallelism": f"sample-striding x{world}",
                        "env_map": None if data.env is None else "synthetic 2048x1024"},
             "spp_per_s": round(a.steps * world / dt, 3), "rays_per_step_per_gpu": round(total_rays / a.steps / world, 1),
-            "shadow_rays": round(total_shadow / a.steps / world, 1), "kernel_ms_per_step": round(cnt.kernel_ms / max(launches_total, 1), 3),
+            "shadow_rays": round(total_shadow / a.steps / world, 1),
+            # kernel_window_ms: mean of the launches' own HIP-event windows (= rocprofv3's average kernel duration); pipelined
+            # launches overlap pairwise, so the windows add up to about twice the time the kernels held the GPU, which is
+            # kernel_span_ms_per_step (first start to last end of a batch / launches)
+            "kernel_window_ms": round(cnt.kernel_ms / max(launches_total, 1), 3),
+            "kernel_span_ms_per_step": round(cnt.kernel_span_ms / max(launches_total, 1), 3) if cnt.kernel_span_ms > 0 else None,
+            # share of the counted rays that are last-level rays traced hit-or-miss (scenes without emitting meshes: such a
+            # ray adds nothing if it hits anything, so it stops at its first hit; same image, cheaper ray), from the CPU sample
+            "anyhit_ray_frac": None if cpu is None else round(cpu["anyhit"], 4),
             "accumulate_ms": round(prof.accumulate_ms / max(launches_total, 1), 3),
             "roofline": roof,
         }
         if a.integrator:
             out["level_ms"] = [round(prof.ms[k] / launches_total, 3) for k in range(depth)]
             out["level_mrays"] = [round(prof.rays[k] / launches_total / 1e6, 2) for k in range(depth)]
+        if world == 1 and not multi and a.trace_loop_frames > 0 and a.integrator == 0:
+            out["trace_loop"] = trace_loop(pt, t, sc, settings, W, H, a.trace_loop_frames)
         if cpu is not None and world == 1:
             out["cpu_baseline"] = {"value": round(cpu["mrays"], 2), "unit": "Mrays/s", "cores": min(os.cpu_count() or 1, 16), "kind": "port",
                                    "sample": f"{cpu['desc']} ({cpu['rays']} rays, {cpu['sec']:.1f} s), same flat BVH"}
@@ -365,22 +423,124 @@ def run_workload(name, a, ctx, cpu_seconds):
     return out
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` with no launcher in the environment: this process becomes the launcher.  It makes no
+    GPU call (torch.cuda.device_count() does not initialise the device), starts N copies of this script -- one rank per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would -- relays rank 0's
+    JSON line to its own stdout and exits with the first non-zero exit code of a rank (the others are stopped by PID).
+    More ranks than visible GPUs is an error, never a silent shrink; --share-gpus lifts it for rehearsals."""
+    import socket
+    import subprocess
+    import threading
+    if not a.rehearse_launch:
+        import torch
+        visible = torch.cuda.device_count()
+        if visible == 0:
+            print(f"bench.py: --gpus {a.gpus} requested but no GPU is visible", file=sys.stderr)
+            return 2
+        if a.gpus > visible and not a.share_gpus:
+            print(f"bench.py: --gpus {a.gpus} requested but only {visible} GPU(s) are visible (a rehearsal with several ranks per GPU needs --share-gpus --backend gloo)", file=sys.stderr)
+            return 2
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_SELF_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+
+    def relay():      # rank 0's JSON line goes to stdout; anything else it prints there (library banners) to stderr
+        for line in procs[0].stdout:
+            dst = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+            dst.write(line); dst.flush()
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    rc = 0
+    live = set(range(a.gpus))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    th.join(timeout=5)
+    return rc
+
+
+def rehearse_rank(a, rank, world):
+    """--rehearse-launch: the N-rank control flow on the CPU and nothing else.  Every rank joins the gloo group, takes
+    its frames by the product's partition rule (dist.frames_for_rank), adds a frame-dependent constant per frame into a
+    small sum buffer instead of rendering, and the closing reduce + scale of the real flow (dist.reduce_accumulation)
+    must return the mean over all frames exactly once each.  No ray is traced and `value` is null: this proves that
+    `bench.py --gpus N` yields N cooperating ranks, not a throughput."""
+    import torch
+    import torch.distributed as dist
+    from cudapathtracer_amd.dist import frames_for_rank, reduce_accumulation
+    dist.init_process_group("gloo")
+    assert dist.get_rank() == rank and dist.get_world_size() == world
+    n_frames = a.steps * world
+    first, count, stride = frames_for_rank(0, n_frames, rank, world)
+    acc = torch.zeros((4, 8, 4))
+    t0 = time.perf_counter()
+    for i in range(count):
+        acc[..., :3] += float(first + i * stride + 1)
+    mean = reduce_accumulation(acc, n_frames, dst=0)
+    v = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, (rank, os.getpid(), count))
+    if rank == 0:
+        want = sum(range(1, n_frames + 1)) / n_frames
+        assert torch.allclose(mean[..., :3], torch.full((4, 8, 3), want)) and (mean[..., 3] == 1).all(), "rehearsal reduce"
+        assert sorted(r for r, _, _ in ranks) == list(range(world)) and len({p for _, p, _ in ranks}) == world
+        print(json.dumps({"metric": "Mrays/s (extension+shadow)", "value": None, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "rehearsal": "launch only: N ranks, gloo rendezvous, frame partition and closing reduce on the CPU; no ray traced, nothing measured",
+                          "frames_per_rank": [c for _, _, c in sorted(ranks)], "config": {"workload": "none (rehearse-launch)", "parallelism": f"sample-striding x{world}"}}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
     if os.environ.get("BENCH_DEBUG"):
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ.get("BENCH_DEBUG_DUMP_AFTER", "40")), exit=False)
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.rehearse_launch):
+        sys.exit(spawn_ranks(a))            # no launcher: become one (before any GPU call)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        # never shrink or grow silently: the line would carry an n_gpus nobody asked for
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} rank(s); start `python bench.py --gpus N` "
+                  f"without a launcher (it spawns its own ranks) or pass the same N to both", file=sys.stderr)
+        sys.exit(2)
+    if a.rehearse_launch:
+        return rehearse_rank(a, rank, world)
     import torch
     import torch.distributed as dist
-    local = local % max(torch.cuda.device_count(), 1)      # rehearsals may put several ranks on one GPU
+    visible = torch.cuda.device_count()
+    if visible == 0:
+        print("bench.py: no GPU visible (there is no CPU fallback; --rehearse-launch rehearses the rank launch alone)", file=sys.stderr)
+        sys.exit(2)
+    if local >= visible and not a.share_gpus:
+        print(f"bench.py: rank {rank} has LOCAL_RANK {local} but only {visible} GPU(s) are visible (--share-gpus allows a rehearsal with several ranks per GPU)", file=sys.stderr)
+        sys.exit(2)
+    if a.share_gpus and world > visible and a.backend == "nccl":
+        print("bench.py: --share-gpus needs --backend gloo (RCCL refuses two ranks on one GPU)", file=sys.stderr)
+        sys.exit(2)
+    local = local % visible      # --share-gpus rehearsals put several ranks on one GPU
     # BENCH_FORCE_COLLECTIVES=1: run the N > 1 flow (process group, warm-up reduce, sum buffers, reduce, all_reduce) with
     # whatever world size there is -- a one-rank rehearsal of the RCCL calls on a one-GPU box
     multi = world > 1 or bool(os.environ.get("BENCH_FORCE_COLLECTIVES"))
-    if a.gpus != world and rank == 0:
-        print(f"note: --gpus {a.gpus} but WORLD_SIZE {world}; using {world} process(es)", file=sys.stderr)
     # order matters twice: torch initialises the GPU before libmipt is loaded (two HIP clients in one process), and the
     # tracer takes its hardware queues (mipt_create) before RCCL creates its streams -- a process has only
     # GPU_MAX_HW_QUEUES of them and the frame pipeline needs two that are not shared

@@ -336,6 +336,41 @@ class Scene:
         self.close()
 
 
+class Buffer:
+    """mipt_buffer: the CUDABuffer work-alike (lazy host / device mirror with the reference's 4-state head)."""
+
+    def __init__(self, tracer, nbytes):
+        self.h = None
+        h = _vp()
+        tracer._chk(lib.mipt_buffer_create(tracer.h, nbytes, C.byref(h)), "buffer_create")
+        self.h, self.nbytes = h, nbytes
+
+    def mutable_gpu_data(self):
+        return lib.mipt_buffer_mutable_gpu_data(self.h)
+
+    def gpu_data(self):
+        return lib.mipt_buffer_gpu_data(self.h)
+
+    def cpu_data(self, dtype=np.uint8):
+        """CUDABuffer::cpu_data(): blocking device-to-host copy when the head is at the GPU; a view of the pinned mirror."""
+        p = lib.mipt_buffer_cpu_data(self.h)
+        if not p:
+            raise MiptError("mipt_buffer_cpu_data failed")
+        return np.frombuffer((C.c_uint8 * self.nbytes).from_address(p), dtype=dtype)
+
+    @property
+    def head(self):
+        return int(lib.mipt_buffer_head(self.h))
+
+    def close(self):
+        if self.h:
+            lib.mipt_buffer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class Tracer:
     def __init__(self, device=0):
         self.h = None

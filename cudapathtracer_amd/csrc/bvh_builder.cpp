@@ -213,6 +213,38 @@ private:
     }
 
     // ---- SBVH ---------------------------------------------------------------------------------------------------
+    // The six functions that follow -- build(const Spec&, int, int64_t), find_object_split, do_object_split, split_ref,
+    // find_spatial_split and do_spatial_split (down to the "---- end of the SBVH core" line) -- restate the algorithm of
+    // the reference's CUDATracer/SplitBVHBuilder.cpp:132-512, which derives from NVIDIA's "Understanding the Efficiency
+    // of Ray Traversal on GPUs" framework and is distributed under the notice below.  That notice covers those six
+    // functions (as adapted here: corrected AABB growth, duplication budget, depth-capped fallback, parallel splice
+    // hooks); nothing else in this file derives from that source.
+    /*
+    *  Copyright (c) 2009-2011, NVIDIA Corporation
+    *  All rights reserved.
+    *
+    *  Redistribution and use in source and binary forms, with or without
+    *  modification, are permitted provided that the following conditions are met:
+    *      * Redistributions of source code must retain the above copyright
+    *        notice, this list of conditions and the following disclaimer.
+    *      * Redistributions in binary form must reproduce the above copyright
+    *        notice, this list of conditions and the following disclaimer in the
+    *        documentation and/or other materials provided with the distribution.
+    *      * Neither the name of NVIDIA Corporation nor the
+    *        names of its contributors may be used to endorse or promote products
+    *        derived from this software without specific prior written permission.
+    *
+    *  THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS" AND
+    *  ANY EXPRESS OR IMPLIED WARRANTIES, INCLUDING, BUT NOT LIMITED TO, THE IMPLIED
+    *  WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A PARTICULAR PURPOSE ARE
+    *  DISCLAIMED. IN NO EVENT SHALL <COPYRIGHT HOLDER> BE LIABLE FOR ANY
+    *  DIRECT, INDIRECT, INCIDENTAL, SPECIAL, EXEMPLARY, OR CONSEQUENTIAL DAMAGES
+    *  (INCLUDING, BUT NOT LIMITED TO, PROCUREMENT OF SUBSTITUTE GOODS OR SERVICES;
+    *  LOSS OF USE, DATA, OR PROFITS; OR BUSINESS INTERRUPTION) HOWEVER CAUSED AND
+    *  ON ANY THEORY OF LIABILITY, WHETHER IN CONTRACT, STRICT LIABILITY, OR TORT
+    *  (INCLUDING NEGLIGENCE OR OTHERWISE) ARISING IN ANY WAY OUT OF THE USE OF THIS
+    *  SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
+    */
     struct ObjSplit { float sah = std::numeric_limits<float>::max(); int dim = 0; int nLeft = 0; Box lb, rb; };
     struct SpaSplit { float sah = std::numeric_limits<float>::max(); int dim = 0; float pos = 0.f; };
 
@@ -402,6 +434,7 @@ private:
         }
         L.n = le - ls; R.n = (int)stk.size() - rs;
     }
+    // ---- end of the SBVH core (the part the NVIDIA notice above covers) -----------------------------------------
 };
 
 // ---- BVH2 -> quantised 4-wide nodes ------------------------------------------------------------------------------

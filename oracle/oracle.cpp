@@ -424,7 +424,7 @@ struct orc_scene {
 namespace {
 
 struct Hit { float t, u, v; int tri; bool front; };   // tri = global id
-struct alignas(128) Counters { uint64_t rays = 0, nodes = 0, tris = 0, hits = 0, shadow = 0; };   // one cache line per thread
+struct alignas(128) Counters { uint64_t rays = 0, nodes = 0, tris = 0, hits = 0, shadow = 0, anyhit = 0; };   // one cache line per thread
 
 // Moller-Trumbore on (v0, e1, e2) -- CUDATracerProg.cu:232-263.  Accepts iff t>0 && t<tmin (strict), or -- when
 // `id`/`bestId` are given (>= 0) -- on an exact tie t==tmin if the candidate's global triangle id is lower.  The
@@ -836,6 +836,7 @@ v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noE
     // last-level ray at its first hit when no mesh of the scene emits -- such a ray adds nothing if it hits anything.  The
     // image is the same either way; only node visits / triangle tests (the roofline's algorithmic counts) change.
     const bool anyhit = k.s->anyhitLast && ttl == 1 && !k.s->anyEmits;
+    if (anyhit) k.c->anyhit++;
     Hit h = isect(*k.s, k.isect, o, d, k.c, anyhit);
     if (h.tri < 0) return noEnv ? color : OnMiss(k, d);
     if (anyhit) return color;
@@ -1120,7 +1121,7 @@ int orc_trace_rays(const orc_scene* s, int mode, const float* origins, const flo
             o.t = h.t; o.u = h.u; o.v = h.v; o.tri = h.tri; o.mesh = h.tri >= 0 ? (int32_t)s->triMesh[h.tri] : -1; o.front = h.front ? 1 : 0;
         }
     });
-    if (stats) { memset(stats, 0, sizeof *stats); for (auto& c : cs) { stats->rays += c.rays; stats->node_visits += c.nodes; stats->tri_tests += c.tris; stats->hits += c.hits; stats->shadow_rays += c.shadow; } }
+    if (stats) { memset(stats, 0, sizeof *stats); for (auto& c : cs) { stats->rays += c.rays; stats->node_visits += c.nodes; stats->tri_tests += c.tris; stats->hits += c.hits; stats->shadow_rays += c.shadow; stats->anyhit_rays += c.anyhit; } }
     return 0;
 }
 
@@ -1158,7 +1159,7 @@ int orc_render(const orc_scene* s, const orc_settings* st, int isect_mode, int r
             }
         });
     }
-    if (stats) { memset(stats, 0, sizeof *stats); for (auto& c : cs) { stats->rays += c.rays; stats->node_visits += c.nodes; stats->tri_tests += c.tris; stats->hits += c.hits; stats->shadow_rays += c.shadow; } }
+    if (stats) { memset(stats, 0, sizeof *stats); for (auto& c : cs) { stats->rays += c.rays; stats->node_visits += c.nodes; stats->tri_tests += c.tris; stats->hits += c.hits; stats->shadow_rays += c.shadow; stats->anyhit_rays += c.anyhit; } }
     return 0;
 }
 

@@ -73,6 +73,7 @@ typedef struct {
     uint64_t tri_tests;   /* triangle tests */
     uint64_t hits;        /* rays that hit something */
     uint64_t shadow_rays; /* of `rays`: occlusion rays of the env-map importance sampling estimator (estimator 1) */
+    uint64_t anyhit_rays; /* of `rays`: last-level rays traced under orc_scene_set_anyhit_last_level's hit-or-miss rule */
 } orc_stats;
 
 typedef struct { float t, u, v; int32_t tri; int32_t mesh; int32_t front; } orc_hit; /* tri = global triangle id, -1 = miss */

@@ -49,7 +49,7 @@ class SceneDesc(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("hits", C.c_uint64),
-                ("shadow_rays", C.c_uint64)]
+                ("shadow_rays", C.c_uint64), ("anyhit_rays", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("tri", "<i4"), ("mesh", "<i4"), ("front", "<i4")])
