@@ -21,25 +21,47 @@ inline void ToFloat(const unsigned char rgbe[4], float* rgb) {
 }
 inline void FromFloat(const float* rgb, unsigned char rgbe[4]) {
     float v = rgb[0]; if (rgb[1] > v) v = rgb[1]; if (rgb[2] > v) v = rgb[2];
-    if (!(v >= 1e-32f)) { rgbe[0] = rgbe[1] = rgbe[2] = rgbe[3] = 0; return; }
+    if (v < 1e-32 || v != v) { rgbe[0] = rgbe[1] = rgbe[2] = rgbe[3] = 0; return; }      // rgbe.c:78 compares in double; NaN (undefined there) -> black
     int e; v = (float)(std::frexp(v, &e) * 256.0 / v);
     rgbe[0] = (unsigned char)(rgb[0] * v); rgbe[1] = (unsigned char)(rgb[1] * v); rgbe[2] = (unsigned char)(rgb[2] * v);
     rgbe[3] = (unsigned char)(e + 128);
 }
 
 // Decodes a whole .hdr image held in memory into float RGB rows (top row first).  Returns false on malformed input.
+// The set of byte strings accepted -- and every pixel of an accepted one -- is that of the reference's reader as
+// DefaultScene/tracer.cpp:130-134 calls it, RGBE_ReadHeader(f, &w, &h, NULL) + RGBE_ReadPixels_RLE (Common/rgbe.c:134-190,
+// 327-412); tests/test_rgbe.py holds this function to the reference's own rgbe.c (compiled unmodified by the test
+// infrastructure) on a corpus of well-formed, odd and damaged files.  What follows from that:
+//  * header lines are what fgets(buf, 128, fp) yields: at most 127 bytes, cut after a newline, compared as C strings;
+//  * the "#?" magic is optional (rgbe.c:149-152: the check is commented out), and the first line goes through the same
+//    loop as every other line;
+//  * an empty line before FORMAT= is an error; the line after "FORMAT=32-bit_rle_rgbe\n" must be exactly "\n"
+//    (rgbe.c:180-184), so GAMMA= / EXPOSURE= / comment lines are only accepted BEFORE the FORMAT line;
+//  * the size line is parsed by sscanf("-Y %d +X %d") (rgbe.c:187).
+// Deviations, all where the reference reads or allocates out of bounds: a size that is not positive is refused (the
+// reference "accepts" it, reads nothing and its caller builds a vector of 3*w*h floats), and a size whose pixel data
+// cannot fit in the bytes that follow is refused before anything is allocated (the reference fails at the first short
+// read, after its caller has allocated).
 inline bool Decode(const unsigned char* p, size_t n, std::vector<float>& rgb, int& width, int& height) {
     size_t pos = 0;
-    auto line = [&](std::string& out) { out.clear(); while (pos < n && p[pos] != '\n') out.push_back((char)p[pos++]); if (pos >= n) return false; pos++; return true; };
+    auto fgets128 = [&](std::string& out) {         // fgets(buf, 128, fp) followed by C-string use of buf
+        out.clear();
+        if (pos >= n) return false;
+        while (pos < n && out.size() < 127) { const char c = (char)p[pos++]; out.push_back(c); if (c == '\n') break; }
+        const size_t z = out.find('\0');
+        if (z != std::string::npos) out.resize(z);
+        return true;
+    };
     std::string l;
-    if (!line(l) || l.size() < 2 || l[0] != '#' || l[1] != '?') return false;
-    bool format = false;
+    if (!fgets128(l)) return false;
     for (;;) {
-        if (!line(l)) return false;
-        if (l == "FORMAT=32-bit_rle_rgbe") format = true;
-        if (l.empty()) break;
+        if (l.empty() || l[0] == '\n') return false;                // "no FORMAT specifier found"
+        if (l == "FORMAT=32-bit_rle_rgbe\n") break;
+        if (!fgets128(l)) return false;
     }
-    if (!format || !line(l) || std::sscanf(l.c_str(), "-Y %d +X %d", &height, &width) != 2 || width <= 0 || height <= 0) return false;
+    if (!fgets128(l) || l != "\n") return false;                     // "missing blank line after FORMAT specifier"
+    if (!fgets128(l) || std::sscanf(l.c_str(), "-Y %d +X %d", &height, &width) < 2) return false;
+    if (width <= 0 || height <= 0) return false;
     {   // the header is untrusted: no allocation before the pixel count is known to fit the bytes that follow.  Flat data
         // takes 4 bytes per pixel; a run-length scanline at least its 4-byte marker plus, per channel, 2 bytes per run of
         // at most 127 pixels.
