@@ -146,6 +146,7 @@ lib.mipt_rgbe_encode.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp, C.c_size_t]
 lib.mipt_rgbe_encode.restype = C.c_size_t
 lib.mipt_test_math.argtypes = [_vp, C.c_int, _vp, _vp, C.c_uint32, _vp]
 lib.mipt_test_rcp_sweep.argtypes = [_vp, C.c_int, C.POINTER(C.c_uint64)]
+lib.mipt_test_stack_guard.argtypes = [_vp, C.POINTER(C.c_uint64)]
 lib.mipt_test_issue.argtypes = [_vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(IssueResult)]
 
 
@@ -479,6 +480,13 @@ class Tracer:
         out = (C.c_uint64 * 4)()
         self._chk(lib.mipt_test_rcp_sweep(self.h, steps, out), "test_rcp_sweep")
         return tuple(int(v) for v in out)
+
+    def test_stack_guard(self):
+        """(bytes of the wave-stack arrays beyond the waves' regions, bytes of those that were overwritten, shade batches cut
+        short for lack of stack room since reset_counters); the first two need option wave_stack_entries"""
+        out = (C.c_uint64 * 3)()
+        self._chk(lib.mipt_test_stack_guard(self.h, out), "test_stack_guard")
+        return int(out[0]), int(out[1]), int(out[2])
 
     def test_issue(self, blocks_per_cu, iters, packed=0):
         """VALU issue calibration (csrc/microbench.hip): returns an IssueResult."""

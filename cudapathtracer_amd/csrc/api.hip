@@ -41,6 +41,8 @@ struct mipt_tracer {
     uint32_t tileRows = 0, tileParts = 1, tilePart = 0;     // mipt_set_tile_partition (tileParts 1: the whole frame)
     int64_t pipelineFrames = 1;      // consecutive frames alternate between two streams / buffer sets (see mipt_render)
     int64_t keepSample = 0;          // 1: a pipelined frame's sample buffer survives its fold (mipt_last_sample), at the price of one clear per frame
+    int64_t waveStackEntries = 0;    // test option "wave_stack_entries": entries per wave the kernel may use (0 = 256 * maxDepth + 256)
+    size_t guardFrom = 0;            // with that option: first entry of the wave-stack arrays no wave may touch (mipt_test_stack_guard)
     // work buffers
     Queue wstack = {}; size_t wstackEntries = 0;
     Queue q[2] = {};
@@ -484,7 +486,8 @@ int mipt_synchronize(mipt_tracer* t) {
         unsigned long long flag = 0;
         HIPCHK(t, hipMemcpy(&flag, t->stats + 39, sizeof flag, hipMemcpyDeviceToHost));
         if (flag) {
-            hipMemset(t->stats + 39, 0, sizeof flag);
+            hipMemsetAsync(t->stats + 39, 0, sizeof flag, t->stream);
+            hipStreamSynchronize(t->stream);
             return fail(t, MIPT_E_LIMIT, "wave stack overflow: a frame lost rays (raise the per-wave capacity)");
         }
         return MIPT_OK;
@@ -504,6 +507,7 @@ int mipt_set_option(mipt_tracer* t, const char* key, int64_t v) {
     else if (k == "xcd_bands") { if (v < -1 || v > 1) return fail(t, MIPT_E_INVALID, "xcd_bands must be -1 (auto), 0 or 1"); t->xcdBands = v; }
         else if (k == "pipeline_frames") t->pipelineFrames = v ? 1 : 0;
         else if (k == "keep_sample") t->keepSample = v ? 1 : 0;
+        else if (k == "wave_stack_entries") { if (v < 0 || v > (1 << 20)) return fail(t, MIPT_E_INVALID, "wave_stack_entries out of range"); t->waveStackEntries = v; }
         else if (k == "estimator") { if (v < 0 || v > 3) return fail(t, MIPT_E_INVALID, "estimator must be 0 (reference), 1 (light sampling), 2 (VNDF + cosine lobes) or 3 (both)"); t->estimator = v; }
         else if (k == "profile_levels") t->profileLevels = v ? 1 : 0;
         else if (k == "integrator") { if (v != 0 && v != 1) return fail(t, MIPT_E_INVALID, "integrator must be 0 (wave stacks) or 1 (level queues)"); t->integrator = v; }
@@ -796,8 +800,11 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
             // depth-first integrator: no queues
         } else if (t->integrator == 0) {
             // persistent wave stacks: 256 entries per recursion level per wave (see k_wavestack), independent of the viewport
-            wcap = (nee ? 512u : 256u) * std::max<uint32_t>(D, 1u) + 256u;      // estimator 1: up to four rays per hit
-            const size_t need = (size_t)persistentBlocks * 4 * wcap;
+            // (a capacity reached in simulation, not a proven bound: a wave that runs out of room stalls its shade phase
+            // instead of overflowing, see k_wavestack A1, so the figure decides speed and not correctness)
+            const uint32_t wcapDefault = (nee ? 512u : 256u) * std::max<uint32_t>(D, 1u) + 256u;      // estimator 1: up to four rays per hit
+            wcap = t->waveStackEntries ? (uint32_t)t->waveStackEntries : wcapDefault;
+            const size_t need = (size_t)persistentBlocks * 4 * std::max(wcap, wcapDefault);
             if (t->wstackEntries < need) {
                 free_queue(t->wstack); t->wstackEntries = 0;
                 HIPCHK(t, hipMalloc((void**)&t->wstack.a, need * sizeof(float4)));
@@ -841,6 +848,23 @@ int mipt_render(mipt_tracer* t, mipt_scene* sc, const mipt_settings* st, uint32_
             if (evenMax >= 2) { rc = ensure_queue(t, 0, (size_t)tile << evenMax); if (rc) return rc; }
         }
 
+        if (t->waveStackEntries && t->integrator == 0 && t->rngMode == MIPT_RNG_NODE) {
+            // test option: every byte of the wave-stack arrays is painted before the call, and mipt_test_stack_guard then
+            // checks that nothing beyond the waves' (shrunken) regions was written
+            join_aux(t);
+            HIPCHK(t, hipStreamSynchronize(t->stream));
+            for (Queue* q : { &t->wstack, &t->wstack2 }) {
+                const size_t n = q == &t->wstack ? t->wstackEntries : t->wstack2Entries;
+                if (!n || !q->a) continue;
+                // (on the tracer's own stream and waited for: a plain hipMemset goes to the null stream, which the tracer's
+                // non-blocking streams do not wait for, and may still be painting when the first frame pushes its rays)
+                HIPCHK(t, hipMemsetAsync(q->a, 0xA5, n * sizeof(float4), t->stream)); HIPCHK(t, hipMemsetAsync(q->b, 0xA5, n * sizeof(float4), t->stream));
+                HIPCHK(t, hipMemsetAsync(q->c, 0xA5, n * sizeof(float4), t->stream));
+            }
+            HIPCHK(t, hipStreamSynchronize(t->stream));
+            t->guardFrom = (size_t)persistentBlocks * 4 * wcap;
+            t->mainTouched = true;
+        }
         if (pipe && t->mainTouched) {       // aux / fold start after whatever else the caller queued on the tracer's stream (clears, uploads ...)
             HIPCHK(t, hipEventRecord(t->joinEv, t->stream));
             HIPCHK(t, hipStreamWaitEvent(t->aux, t->joinEv, 0));
@@ -1197,6 +1221,35 @@ int mipt_test_math(mipt_tracer* t, int fn, const float* a, const float* b, uint3
         HIPCHK(t, hipStreamSynchronize(t->stream));
         HIPCHK(t, hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
         hipFree(da); hipFree(db); hipFree(dout);
+        return MIPT_OK;
+    });
+}
+
+// Test support for option "wave_stack_entries": out[0] = bytes of the wave-stack arrays beyond the waves' regions,
+// out[1] = how many of them no longer hold the paint mipt_render put there (must be 0: a wave never writes past its stack),
+// out[2] = shade batches cut short or put off for lack of stack room since the last mipt_reset_counters (any capacity).
+int mipt_test_stack_guard(mipt_tracer* t, uint64_t out[3]) {
+    return guarded(t, [&]() -> int {
+        if (!t || !out) return MIPT_E_INVALID;
+        if (use(t)) return MIPT_E_HIP;
+        HIPCHK(t, hipStreamSynchronize(t->stream));
+        out[0] = out[1] = out[2] = 0;
+        unsigned long long cut = 0;
+        HIPCHK(t, hipMemcpy(&cut, t->stats + 36, sizeof cut, hipMemcpyDeviceToHost));
+        out[2] = cut;
+        if (!t->waveStackEntries) return MIPT_OK;          // no paint, nothing to check: only the counter
+        std::vector<unsigned char> h;
+        for (Queue* q : { &t->wstack, &t->wstack2 }) {
+            const size_t n = q == &t->wstack ? t->wstackEntries : t->wstack2Entries;
+            if (!n || !q->a || n <= t->guardFrom) continue;
+            const size_t bytes = (n - t->guardFrom) * sizeof(float4);
+            h.resize(bytes);
+            for (float4* arr : { q->a, q->b, q->c }) {
+                HIPCHK(t, hipMemcpy(h.data(), arr + t->guardFrom, bytes, hipMemcpyDeviceToHost));
+                out[0] += bytes;
+                for (unsigned char c : h) if (c != 0xA5) out[1]++;
+            }
+        }
         return MIPT_OK;
     });
 }

@@ -664,6 +664,7 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
     uint32_t deep[LDS_SCENE ? 1 : (WIDE ? kWideStackCap : kStackCap) - kLdsStack];
     int tsp = 0;
     uint32_t traced = 0, shadowTraced = 0;
+    uint32_t nShort = 0;              // wave-uniform
     MIPT_PROF(unsigned long long pf[12] = {};)
     // Work that cannot change the image is not done (the rays are still traced and counted):
     //  * a ray that ends (miss, or hit at the last level) without anything to add -- black analytic sky, non-emitting
@@ -680,8 +681,21 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
         const bool pressure = nF + nT > (uint32_t)kSqCap - 32u;      // little room left for rays that terminate next
 
         // ---- A1. shade a batch of "full" records: every lane runs the whole bounce and pushes two children ----------
+        // A batch never pushes past the wave's stack: it shades as many records as the stack has room for the children of
+        // (two per record, four with light sampling), and none -- the wave is then `stalled` -- when there is no room at
+        // all.  A stalled wave goes on with everything that frees room: terminal batches, refills (from one idle lane on),
+        // traversal, parking.  Only when none of those can move either -- stack full, shade queue full of records that want
+        // to spawn, every lane holding a finished ray it cannot park -- is there nothing left to wait for: that one state
+        // drops a batch's children and raises the overflow flag (mipt_synchronize: MIPT_E_LIMIT), so every wave still
+        // reaches its exit.  The capacity the host picks (256 x maxDepth + 256 entries) therefore decides speed, not
+        // correctness: a stack a tenth of that size renders the same ray trees (tests: test_small_wave_stack_*).
+        bool stalled = false;
         if (nF >= 64u || (nF > 0u && (starving || (pressure && nF >= nT)))) {
-            const uint32_t n = nF < 64u ? nF : 64u;
+            const uint32_t room = (A.cap - sp) / (NEE ? 4u : 2u);
+            uint32_t n = nF < 64u ? nF : 64u;
+            if (room < n) { n = room; nShort++; }           // (counted: stats[36] shade batches cut short or put off for lack of room)
+            stalled = n == 0u;
+        if (!stalled) {
             nF -= n;
             MIPT_PROF(pf[6]++; pf[7] += n;)
             const bool has = lane < n;
@@ -743,9 +757,7 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
             const bool takeOwn = !NEE && has && !active;
             const unsigned long long tk = NEE ? 0ull : MIPT_BALLOT(takeOwn);
             const uint32_t total = 2u * n + nEnvRays + (uint32_t)__popcll(em) - (uint32_t)__popcll(tk);
-            if (sp + total > A.cap) {
-                if (lane == 0) atomicOr(A.stats + 39, 1ull);       // overflow: reported by the host, never written past
-            } else {
+            {       // (sp + total <= cap by the choice of n)
                 if (has) {
                     const uint32_t w = sp + 2u * lane - (uint32_t)__popcll(tk & below);
                     uint32_t flags2 = 0;
@@ -784,6 +796,7 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
             }
             continue;
         }
+        }
         // ---- A2. a batch of terminal records: miss radiance, or the emission of a hit at the last level -------------
         if (nT >= 64u || (nT > 0u && (starving || pressure))) {
             const uint32_t n = nT < 64u ? nT : 64u;
@@ -809,7 +822,8 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
         }
 
         // ---- B. refill idle lanes: new primaries in the lowest ranks, then the top of the wave's stack --------------
-        if (idle >= A.refill && (sp > 0u || more)) {
+        uint32_t refilled = 0;
+        if (idle >= (stalled ? 1u : A.refill) && (sp > 0u || more)) {
             const uint32_t take = sp < idle ? sp : idle;
             uint32_t got = 0, pbase = 0;
             if (more && take < idle) {
@@ -837,6 +851,7 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                 }
             }
             sp -= take;
+            refilled = take + got;
             MIPT_PROF(pf[10]++; pf[11] += take + got;)
             if (!active) {
                 const uint32_t rank = (uint32_t)__popcll(~actMask & below);
@@ -871,6 +886,10 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
         const uint32_t nActive = (uint32_t)__popcll(roundActive);
         if (nActive == 0u) {
             if (nF + nT == 0u) break;
+            if (stalled) {          // nothing in flight and no room to shade into: a stack smaller than one record's children
+                if (lane == 0) atomicOr(A.stats + 39, 1ull);
+                nF -= nF < 64u ? nF : 64u;
+            }
             continue;
         }
 
@@ -977,6 +996,10 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                   pf[4] += wave_max_u32(myTris); pf[5] += wave_sum_u32(myTris);)
         bool fin = active && cur == kTerm;
         unsigned long long fm = MIPT_BALLOT(fin);
+        // the one state a stalled wave cannot leave by itself (see A1): no lane refilled, none still traversing, and -- checked
+        // below -- none of the finished ones able to park or retire
+        const bool stuck = stalled && refilled == 0u && (fm == roundActive);
+        uint32_t moved = 0;
         if (fm) {
             const uint32_t level = 31u - (uint32_t)__clz((int)node);             // root = 1 -> level 0
             const bool term = h.tri < 0 || level + 1 >= A.F.maxDepth              // children would have ttl 0 (CUDATracerProg.cu:433)
@@ -987,7 +1010,9 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                                             : (shadow || !(__float_as_uint(h.u) >> 31) || (NEE && (pix & kNoEmitBit)));
                 if (dead) { active = false; fin = false; }
             }
+            moved = (uint32_t)__popcll(fm);
             fm = MIPT_BALLOT(fin);
+            moved -= (uint32_t)__popcll(fm);          // retired on the spot
             // no room: stay terminated-but-unparked until the queue has been drained
             fin = fin && nF + nT + (uint32_t)__popcll(fm & below) < (uint32_t)kSqCap;
             const unsigned long long mF = MIPT_BALLOT(fin && !term), mT = MIPT_BALLOT(fin && term);
@@ -1003,11 +1028,17 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                 active = false;
             }
             nF += (uint32_t)__popcll(mF); nT += (uint32_t)__popcll(mT);
+            moved += (uint32_t)__popcll(mF | mT);
+        }
+        if (stuck && moved == 0u) {       // overflow: the children of one batch are lost, the host reports it, nothing is written past the stack
+            if (lane == 0) atomicOr(A.stats + 39, 1ull);
+            nF -= nF < 64u ? nF : 64u;
         }
     }
     // one counter update per wave
     for (int sh = 32; sh > 0; sh >>= 1) traced += __shfl_down(traced, sh);
     if (lane == 0 && traced) atomicAdd(A.stats, (unsigned long long)traced);
+    if (lane == 0 && nShort) atomicAdd(A.stats + 36, (unsigned long long)nShort);
     if constexpr (NEE) {
         for (int sh = 32; sh > 0; sh >>= 1) shadowTraced += __shfl_down(shadowTraced, sh);
         if (lane == 0 && shadowTraced) atomicAdd(A.stats + 38, (unsigned long long)shadowTraced);

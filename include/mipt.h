@@ -253,6 +253,16 @@ size_t   mipt_rgbe_encode(const float* rgb, uint32_t width, uint32_t height, uns
 /* fn 0 sin 1 cos 2 atan2(a,b) 3 acos 4 x^(1/2.2) 5 x^5 6 x^10 ; host arrays */
 int  mipt_test_math(mipt_tracer*, int fn, const float* a, const float* b, uint32_t n, float* out);
 
+/* ---- wave-stack capacity test support (no counterpart in the reference, which recurses on an 8 KiB local stack,
+ * CUDATracerProg.cu:928) ------------------------------------------------------------------------------------------------
+ * Option "wave_stack_entries" = k > 0 makes the integrator's waves use only k entries each of their pending-ray stacks
+ * (default 256 * maxDepth + 256; the arrays keep their size and are painted before every mipt_render).  A wave that runs
+ * out of room stalls its shade phase and renders the same image, slower; only a stack that cannot even hold one record's
+ * children loses rays, and then mipt_synchronize returns MIPT_E_LIMIT.  mipt_test_stack_guard: out[0] = bytes of the
+ * arrays beyond the waves' regions, out[1] = how many of those bytes were overwritten (always 0) -- both 0 without the
+ * option --, out[2] = shade batches cut short or put off for lack of room since the last mipt_reset_counters. */
+int  mipt_test_stack_guard(mipt_tracer*, uint64_t out[3]);
+
 /* ---- VALU issue calibration (no counterpart in the reference; evidence for bench.py's VALU roofline) --------------
  * Launches, on the integrator's grid shape (256-thread blocks, CUs x blocks_per_cu blocks = blocks_per_cu waves per
  * SIMD), a kernel in which every wave issues iters x 64 independent v_fma_f32, and reports the HIP-event time of the

@@ -841,3 +841,144 @@ def test_xcd_bands_render_the_same_frame(tracer, ptlib, oracle, name, w, h, dept
         tracer.set_option("count_pixel_rays", 0)
         s.frameID = 0
         tracer.free(acc), tracer.free(ldr)
+
+
+# ---- wave-stack capacity: a wave that runs out of room stalls, it does not overflow (k_wavestack A1) ----------------------
+def test_short_wave_stack_stalls_and_renders_the_same_ray_trees(tracer, ptlib, oracle):
+    """test option wave_stack_entries.  The host gives every wave 256 * maxDepth + 256 entries; the capacity sweep
+    (profiles/r3/exp_stack_capacity.log) sees the first shade batch cut short below 1024 entries at 1080p, whatever the
+    depth.  With 512 entries per wave a full 1080p Cornell frame at depth 8 does run short -- the counter says how often --
+    and the waves stall their shade phase instead of overflowing: every pixel still has the oracle's ray tree, synchronize
+    reports nothing, and no byte beyond the waves' regions is written."""
+    data = ptlib.builtin_scene(0)
+    sc = ptlib.Scene(tracer, data)
+    o = oracle.Scene(data)
+    o.set_flat_bvh(*sc.flat())
+    W, H = 1920, 1080
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), W, H, 8)
+    ref = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, 1, want_ldr=False, nthreads=16)
+    acc, _ = dev_buffers(tracer, W, H, ldr=False)
+    tracer.set_option("count_pixel_rays", 1)
+    tracer.set_option("wave_stack_entries", 512)
+    try:
+        tracer.reset_counters()
+        tracer.trace(sc, s, acc, None)
+        tracer.synchronize()                                   # MIPT_E_LIMIT would raise here
+        rgb, rays = tracer.last_sample(W * H, rays=True)
+        checked, touched, cut = tracer.test_stack_guard()
+        assert cut > 100, cut                                  # the stall path did run
+        assert checked > 1 << 20 and touched == 0
+        assert np.array_equal(rays.reshape(H, W), ref["rays"])
+        assert rel_err(rgb.reshape(H, W, 3), ref["sample"]).max() < 2 * RTOL      # the adds into a pixel come in another order than usual
+    finally:
+        tracer.set_option("wave_stack_entries", 0)
+        tracer.set_option("count_pixel_rays", 0)
+        tracer.free(acc)
+
+
+@pytest.mark.parametrize("name,depth,estimator", [("cornell", 8, 0), ("default", 7, 0), ("cornell", 5, 1)])
+def test_tiny_wave_stack_is_exact_or_reported(tracer, ptlib, oracle, name, depth, estimator):
+    """far below any sensible capacity (6 ... 300 entries per wave) the stalled waves can reach the one state nothing leaves
+    by itself -- stack full, shade queue full, every lane holding a finished ray -- and drop a batch's children; that is
+    ALWAYS reported (MIPT_E_LIMIT from mipt_synchronize).  So a frame is either reported or has the oracle's ray tree in
+    every pixel; never silently wrong, and never a byte written past the stacks."""
+    which, cam_kw, env, _, _ = MG.CONFIGS[name]
+    data = MG.scene_data(name)
+    sc = ptlib.Scene(tracer, data)
+    o = oracle.Scene(data)
+    o.set_flat_bvh(*sc.flat())
+    o.set_estimator(estimator)
+    W, H = 96, 64
+    s = ptlib.make_settings(ptlib.make_camera(**cam_kw), W, H, depth)
+    ref = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, 1, nthreads=16)
+    acc, ldr = dev_buffers(tracer, W, H)
+    tracer.set_option("count_pixel_rays", 1)
+    tracer.set_option("estimator", estimator)
+    exact = 0
+    try:
+        for cap in (6, 40, 300):
+            tracer.set_option("wave_stack_entries", cap)
+            tracer.trace(sc, s, acc, ldr)
+            try:
+                tracer.synchronize()
+            except ptlib.MiptError as e:
+                assert "-5" in str(e) and "wave stack overflow" in str(e)
+                reported = True
+            else:
+                reported = False
+            rgb, rays = tracer.last_sample(W * H, rays=True)
+            checked, touched, _ = tracer.test_stack_guard()
+            assert checked > 1 << 20 and touched == 0, (cap, checked, touched)
+            if reported:
+                assert (rays.reshape(H, W) <= ref["rays"]).all()          # rays were lost, none invented
+                continue
+            exact += 1
+            assert np.array_equal(rays.reshape(H, W), ref["rays"]), cap
+            assert rel_err(rgb.reshape(H, W, 3), ref["sample"]).max() < 2 * RTOL, cap
+        assert exact >= 1
+    finally:
+        tracer.set_option("wave_stack_entries", 0)
+        tracer.set_option("estimator", 0)
+        tracer.set_option("count_pixel_rays", 0)
+        tracer.free(acc), tracer.free(ldr)
+
+
+def test_short_wave_stack_under_the_frame_pipeline(tracer, ptlib):
+    """the same through mipt_render's pipelined frames (two stack sets, two streams): 8 frames at 720p with 512-entry stacks
+    equal 8 frames with the default capacity, ray for ray"""
+    sc = ptlib.Scene(tracer, ptlib.builtin_scene(0))
+    W, H = 1280, 720
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), W, H, 8)
+    out = []
+    for cap in (0, 512):
+        acc, _ = dev_buffers(tracer, W, H, ldr=False)
+        tracer.set_option("wave_stack_entries", cap)
+        tracer.reset_counters()
+        try:
+            tracer.render(sc, s, 0, 8, acc)
+            tracer.synchronize()
+            checked, touched, cut = tracer.test_stack_guard()
+            assert (cut > 0) == (cap > 0)
+            if cap:
+                assert checked > 1 << 20 and touched == 0
+        finally:
+            tracer.set_option("wave_stack_entries", 0)
+        out.append((tracer.download(acc, (H, W, 4), np.float32), tracer.counters().rays))
+        tracer.free(acc)
+    assert out[1][1] == out[0][1]
+    assert rel_err(out[1][0], out[0][0]).max() < RTOL * 4
+
+
+def test_wave_stack_overflow_is_reported_and_the_next_frame_is_right(tracer, ptlib, oracle):
+    """a stack that cannot hold even one record's children (1 entry) always loses rays: the waves still end,
+    mipt_synchronize returns MIPT_E_LIMIT once, nothing is written past the stacks, and the next frame at the normal
+    capacity is the oracle's again"""
+    data = ptlib.builtin_scene(0)
+    sc = ptlib.Scene(tracer, data)
+    W, H = 96, 64
+    s = ptlib.make_settings(ptlib.make_camera(**ptlib.CORNELL_CAMERA), W, H, 8)
+    acc, ldr = dev_buffers(tracer, W, H)
+    tracer.set_option("count_pixel_rays", 1)
+    try:
+        tracer.set_option("wave_stack_entries", 1)
+        tracer.trace(sc, s, acc, ldr)
+        with pytest.raises(ptlib.MiptError, match="-5.*wave stack overflow"):
+            tracer.synchronize()
+        checked, touched, _ = tracer.test_stack_guard()
+        assert checked > 1 << 20 and touched == 0
+        _, rays = tracer.last_sample(W * H, rays=True)
+        assert rays.max() <= 3 and rays.sum() >= W * H            # primaries (and what idle lanes took over directly); nothing deeper
+        tracer.synchronize()                                       # the flag was cleared by the report
+        tracer.set_option("wave_stack_entries", 0)
+        tracer.memset(acc, 0, W * H * 16)
+        tracer.trace(sc, s, acc, ldr)
+        tracer.synchronize()
+        rgb, rays = tracer.last_sample(W * H, rays=True)
+        o = oracle.Scene(data)
+        o.set_flat_bvh(*sc.flat())
+        ref = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, 1, nthreads=16)
+        assert np.array_equal(rays.reshape(H, W), ref["rays"]) and rel_err(rgb.reshape(H, W, 3), ref["sample"]).max() < RTOL
+    finally:
+        tracer.set_option("wave_stack_entries", 0)
+        tracer.set_option("count_pixel_rays", 0)
+        tracer.free(acc), tracer.free(ldr)
