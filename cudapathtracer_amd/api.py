@@ -16,6 +16,10 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build it with `make -C cudapathtracer_amd/csrc` (or __graft_entry__.build()); "
         "there is no CPU fallback for the path tracer")
 lib = C.CDLL(LIB_PATH)
+ABI_VERSION = 3         # include/mipt.h MIPT_ABI_VERSION this binding's struct layouts were written against
+lib.mipt_abi_version.restype = C.c_uint32
+if lib.mipt_abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} has ABI version {lib.mipt_abi_version()}, this binding was written for {ABI_VERSION}: rebuild the library")
 
 
 # ---- PODs (sizes asserted against the reference layout in tests/test_abi.py) ------------------------------------

@@ -18,6 +18,9 @@ namespace detail {
 // no device/context argument (they use the current CUDA device, CUDABuffer.cpp:226-240).
 inline mipt_tracer* DefaultTracer() {
     static mipt_tracer* t = [] {
+        // the library writes the structs of the header it was built with: refuse one built against another version
+        if (mipt_abi_version() != MIPT_ABI_VERSION)
+            throw std::runtime_error("libmipt ABI version " + std::to_string(mipt_abi_version()) + " != header version " + std::to_string(MIPT_ABI_VERSION));
         const char* e = std::getenv("MIPT_DEVICE");
         mipt_tracer* h = nullptr;
         int rc = mipt_create(e ? std::atoi(e) : 0, &h);

@@ -9,6 +9,8 @@
 
 #include <chrono>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -30,14 +32,34 @@ namespace {
 int fail(mipt_dist* d, int code, const std::string& msg) { try { if (d) d->err = msg; } catch (...) {} return code; }
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// runs f(rank) on one host thread per GPU and returns the first non-zero status
+// include/mipt_dist.h inherits mipt.h's rule that no entry point throws: every extern "C" body that can allocate on the
+// host runs inside this guard (the same shape as api.hip's)
+template <typename F> int guarded(mipt_dist* d, F&& body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc&) { return fail(d, MIPT_E_NOMEM, "out of host memory"); }
+    catch (const std::exception& e) { try { if (d) d->err = std::string("exception: ") + e.what(); } catch (...) {} return MIPT_E_INVALID; }
+    catch (...) { return fail(d, MIPT_E_INVALID, "unknown exception"); }
+}
+
+// runs f(rank) on one host thread per GPU and returns the first non-zero status.  A thread that cannot be started (or a
+// vector that cannot grow) must not leave joinable threads behind -- their destructors would call std::terminate -- so
+// the ones already running are joined before the failure is reported.
 template <typename F> int per_gpu(mipt_dist* d, F f) {
     std::vector<int> rc(d->n, 0);
     std::vector<std::thread> th;
-    for (int r = 1; r < d->n; r++) th.emplace_back([&, r]() { try { rc[r] = f(r); } catch (...) { rc[r] = MIPT_E_NOMEM; } });
-    try { rc[0] = f(0); } catch (...) { rc[0] = MIPT_E_NOMEM; }
-    for (auto& t : th) t.join();
-    for (int r = 0; r < d->n; r++) if (rc[r]) return fail(d, rc[r], "rank " + std::to_string(r) + ": " + mipt_last_error(d->tracer[r]));
+    bool spawned = true;
+    try {
+        th.reserve(d->n);
+        for (int r = 1; r < d->n; r++) th.emplace_back([&, r]() { try { rc[r] = f(r); } catch (...) { rc[r] = MIPT_E_NOMEM; } });
+    } catch (...) { spawned = false; }
+    if (spawned) { try { rc[0] = f(0); } catch (...) { rc[0] = MIPT_E_NOMEM; } }
+    for (auto& t : th) if (t.joinable()) t.join();
+    if (!spawned) return fail(d, MIPT_E_NOMEM, "could not start one host thread per GPU");
+    for (int r = 0; r < d->n; r++) if (rc[r]) {
+        const char* why = mipt_last_error(d->tracer[r]);
+        try { d->err = "rank " + std::to_string(r) + ": " + why; } catch (...) {}
+        return rc[r];
+    }
     return MIPT_OK;
 }
 void free_buffers(mipt_dist* d) {
@@ -59,6 +81,7 @@ int mipt_dist_frames_for_rank(uint32_t first_frame, uint32_t n_frames, int rank,
 int mipt_dist_create(int n_gpus, mipt_dist** out) {
     if (!out) return MIPT_E_INVALID;
     *out = nullptr;
+    return guarded(nullptr, [&]() -> int {
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return MIPT_E_NODEVICE;
     if (n_gpus == 0) n_gpus = visible;
@@ -75,7 +98,8 @@ int mipt_dist_create(int n_gpus, mipt_dist** out) {
         int rc = mipt_create(r, &d->tracer[r]);
         if (rc) { mipt_dist_destroy(d); return rc; }
     }
-    std::vector<int> devs(n_gpus);
+    std::vector<int> devs;
+    try { devs.resize(n_gpus); } catch (...) { mipt_dist_destroy(d); return MIPT_E_NOMEM; }
     for (int r = 0; r < n_gpus; r++) devs[r] = r;
     if (ncclCommInitAll(d->comm.data(), n_gpus, devs.data()) != ncclSuccess) { mipt_dist_destroy(d); return MIPT_E_HIP; }
     for (int r = 0; r < n_gpus; r++) {
@@ -83,6 +107,7 @@ int mipt_dist_create(int n_gpus, mipt_dist** out) {
     }
     *out = d;
     return MIPT_OK;
+    });
 }
 
 void mipt_dist_destroy(mipt_dist* d) {
@@ -103,6 +128,7 @@ mipt_tracer* mipt_dist_tracer(mipt_dist* d, int rank) { return d && rank >= 0 &&
 
 int mipt_dist_scene_create(mipt_dist* d, const mipt_scene_desc* desc) {
     if (!d || !desc) return MIPT_E_INVALID;
+    return guarded(d, [&]() -> int {
     for (int r = 0; r < d->n; r++) if (d->scene[r]) { mipt_synchronize(d->tracer[r]); mipt_scene_destroy(d->scene[r]); d->scene[r] = nullptr; }
     const bool cache = desc->bvhCachePath && desc->bvhCachePath[0];
     if (cache) {       // rank 0 builds and writes the file; the others load it
@@ -110,10 +136,12 @@ int mipt_dist_scene_create(mipt_dist* d, const mipt_scene_desc* desc) {
         if (rc) return fail(d, rc, std::string("rank 0: ") + mipt_last_error(d->tracer[0]));
     }
     return per_gpu(d, [&](int r) { return d->scene[r] ? MIPT_OK : mipt_scene_create(d->tracer[r], desc, &d->scene[r]); });
+    });
 }
 
 int mipt_dist_render(mipt_dist* d, const mipt_settings* st, uint32_t first_frame, uint32_t n_frames, float* acc_mean_host, unsigned char* ldr_host) {
     if (!d || !st) return MIPT_E_INVALID;
+    return guarded(d, [&]() -> int {
     if (!d->scene[0]) return fail(d, MIPT_E_INVALID, "no scene: call mipt_dist_scene_create first");
     const size_t pixels = (size_t)st->viewportWidth * st->viewportHeight;
     if (!pixels || !n_frames) return fail(d, MIPT_E_INVALID, "empty viewport or no frames");
@@ -161,6 +189,7 @@ int mipt_dist_render(mipt_dist* d, const mipt_settings* st, uint32_t first_frame
     for (int r = 0; r < d->n; r++) d->stats.rays += after[r].rays - before[r].rays;
     d->stats.render_s = t1 - t0; d->stats.reduce_s = now() - t1; d->stats.frames = n_frames; d->stats.gpus = d->n;
     return MIPT_OK;
+    });
 }
 
 int mipt_dist_get_stats(const mipt_dist* d, mipt_dist_stats* out) { if (!d || !out) return MIPT_E_INVALID; *out = d->stats; return MIPT_OK; }

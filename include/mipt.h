@@ -91,6 +91,14 @@ typedef struct {
 
 typedef struct { float t, u, v; int32_t tri; int32_t mesh; int32_t front; } mipt_hit;   /* tri = global triangle id, -1 = miss */
 
+/* ---- ABI version (no counterpart in the reference) -------------------------------------------------------------------
+ * Public structs of this header grow at their end from one version to the next (mipt_counters gained kernel_span_ms in
+ * version 2) and the library writes all of the struct it was built with: a caller compiled against another version must
+ * not run.  The wrappers (cudapathtracer_amd/cpp/CUDABuffer.hpp DefaultTracer, cudapathtracer_amd/api.py) compare
+ * mipt_abi_version() with the MIPT_ABI_VERSION they were compiled / written against before the first call. */
+#define MIPT_ABI_VERSION 3
+uint32_t mipt_abi_version(void);
+
 /* ---- tracer: PathTracer ctor/dtor (CUDATracer.cpp:8-148, CUDATracerProg.cu:925-935) ---------------------- */
 int  mipt_create(int device, mipt_tracer** out);
 void mipt_destroy(mipt_tracer*);
@@ -177,7 +185,12 @@ uint64_t mipt_scene_get_emitters(const mipt_scene*, float* tris, float* cdf, uin
 int  mipt_trace(mipt_tracer*, mipt_scene*, const mipt_settings*, float* acc_dev, unsigned char* ldr_dev);
 /* batched form of the same loop (RendererWindow::render called n_frames times, Common/RendererWindow.hpp:128-148):
  * frames first_frame .. first_frame+n_frames-1; running mean unless sum_mode != 0 (then acc += sample, for
- * multi-GPU sample striding where the caller reduces and scales). frame_stride lets rank r render r, r+G, ... */
+ * multi-GPU sample striding where the caller reduces and scales). frame_stride lets rank r render r, r+G, ...
+ * Asynchronous like mipt_trace: acc_dev / ldr_dev are complete once mipt_synchronize (or any other entry point on the
+ * tracer) has returned.  In sum mode without an LDR target the integrator adds into a block buffer of the tracer's that is
+ * folded into acc_dev every 64 frames and at that point at the latest, so that no contribution is ever added to a sum of
+ * more than 64 frames (a sum of thousands of frames swallows the faint ones: measured -1e-4 of the image mean after 8192
+ * frames when every ray added straight into acc_dev). */
 int  mipt_render(mipt_tracer*, mipt_scene*, const mipt_settings*, uint32_t first_frame, uint32_t n_frames,
                  uint32_t frame_stride, int sum_mode, float* acc_dev, unsigned char* ldr_dev);
 /* mipt_trace for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
@@ -188,7 +201,9 @@ int  mipt_render(mipt_tracer*, mipt_scene*, const mipt_settings*, uint32_t first
  * queues everything on the tracer's stream.  Limits (MIPT_E_LIMIT beyond them): viewportWidth * viewportHeight <= 65536,
  * maxDepth <= 8; needs integrator 0, rng_mode node, estimator 0 or 2, no tile partition, count_pixel_rays off.  All
  * calls on one GPU share the array (what must start at zero is cleared per call): calls that overlap on one GPU --
- * two tracers, or a caller-supplied stream running beside another -- race. */
+ * two tracers, or a caller-supplied stream running beside another -- race.  Under stream capture: hand the capturing
+ * stream over with mipt_set_stream first (it joins whatever mipt_render has in flight before it switches); the call then
+ * records two memsets and two kernels into the capture and nothing else (tests/test_zz_no_alloc.py replays such a graph). */
 int  mipt_trace_static(mipt_tracer*, mipt_scene*, const mipt_settings*, float* acc_dev, unsigned char* ldr_dev);
 /* accumulate-free tonemap of an accumulation buffer (scale applied first): CUDATracerProg.cu:908-919 */
 int  mipt_tonemap(mipt_tracer*, const float* acc_dev, float scale, uint32_t n_pixels, unsigned char* ldr_dev);

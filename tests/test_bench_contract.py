@@ -128,9 +128,20 @@ def test_bench_never_shrinks_the_rank_count_silently():
     assert r.returncode == 2 and not lines and "WORLD_SIZE=1" in r.stderr
 
 
+def visible_gpus():
+    """device count from the HIP runtime libmipt is linked against -- NOT through torch: importing torch into the test
+    process brings its own copy of the runtime along, and the raw-stream tests that follow then talk to the wrong one"""
+    import ctypes as C
+    try:
+        hip = C.CDLL("libamdhip64.so")
+    except OSError:
+        return 0
+    n = C.c_int(0)
+    return n.value if hip.hipGetDeviceCount(C.byref(n)) == 0 else 0
+
+
 def test_bench_without_a_gpu_fails_loudly():
-    import torch
-    if torch.cuda.device_count() > 0:
+    if visible_gpus() > 0:
         pytest.skip("a GPU is visible")
     for args in (["--gpus", "2"], ["--gpus", "1"]):
         r, lines = run_bench(args)
@@ -139,8 +150,7 @@ def test_bench_without_a_gpu_fails_loudly():
 
 @pytest.mark.gpu
 def test_bench_refuses_more_gpus_than_are_visible():
-    import torch
-    n = torch.cuda.device_count() + 1
+    n = visible_gpus() + 1
     r, lines = run_bench(["--gpus", str(n), "--workload", "cornell", "--width", "64", "--height", "64"])
     assert r.returncode != 0 and not lines and "visible" in r.stderr
 

@@ -199,5 +199,5 @@ def test_hdr_file_to_env_map_to_on_miss_equals_the_oracle_fed_by_the_references_
         tracer.free(acc)
         r = o.render(s, oracle.ISECT_FLAT, oracle.RNG_NODE, oracle.MATH_DET, 0, 1)
         assert np.array_equal(rgb.reshape(64, 96, 3), r["sample"])
-        assert len(np.unique(rgb)) > 50            # the frame does see the patches
+        assert len(np.unique(rgb)) > 10            # the frame does see the patches (few of them towards a pole)
     sc.close()
