@@ -93,6 +93,7 @@ struct mipt_tracer {
 struct mipt_scene {
     mipt_tracer* t = nullptr;
     SceneDev dev = {};
+    void* dNodes2 = nullptr; void* dRefs2 = nullptr; size_t nodes2Bytes = 0, refs2Bytes = 0;     // pair layout for k_wavestack (kernels.h)
     void* dNodes = nullptr; void* dRefs = nullptr; void* dShade = nullptr; void* dMats = nullptr; void* dEnv = nullptr; void* dEnvCdf = nullptr;
     std::vector<float> hEnvCdf;
     void* dEmitTri = nullptr; void* dEmitCdf = nullptr;
@@ -407,6 +408,43 @@ void fill_materials(const mipt_scene_desc* d, std::vector<float>& mats) {
     }
 }
 
+// Pair layout of the reference records for k_wavestack (kernels.h SceneDev::nodes2 / refs2): every leaf's references are
+// rewritten as ceil(count / 2) records of 24 floats holding two triangles component by component, an odd leaf's last
+// record is completed by a zero-area pad (e1 = e2 = 0: |det| = 0 < eps, never accepted), and a copy of the node array
+// carries the pair index in the low 27 bits of each leaf reference.  Same triangles, same order within a leaf.
+void build_pairs(const std::vector<float>& nodes, const std::vector<float>& refs, uint32_t width, std::vector<float>& nodes2, std::vector<float>& refs2) {
+    nodes2 = nodes;
+    refs2.clear();
+    refs2.reserve(refs.size() + 24);
+    const size_t nNodes = nodes.size() / 16;
+    const uint32_t nChild = width == 4 ? 4u : 2u;
+    for (size_t n = 0; n < nNodes; n++) {
+        for (uint32_t c = 0; c < nChild; c++) {
+            uint32_t ref; memcpy(&ref, &nodes[n * 16 + 12 + c], 4);
+            if (!(ref & 0x80000000u)) continue;
+            const uint32_t cnt = (ref >> 27) & 0xFu, first = ref & 0x07FFFFFFu;
+            if (!cnt) continue;
+            const uint32_t pair0 = (uint32_t)(refs2.size() / 24);
+            for (uint32_t k = 0; k < cnt; k += 2) {
+                float rec[24] = {};
+                const uint32_t padId = 0x7FFFFFFFu;
+                for (uint32_t h = 0; h < 2; h++) {
+                    if (k + h < cnt) {
+                        const float* R = &refs[(size_t)(first + k + h) * 12];
+                        rec[0 + h] = R[0]; rec[2 + h] = R[1]; rec[4 + h] = R[2]; rec[6 + h] = R[3];            // v0, triangle id
+                        rec[8 + h] = R[4]; rec[10 + h] = R[5]; rec[12 + h] = R[6]; rec[14 + h] = R[11];        // e1, flags
+                        rec[16 + h] = R[8]; rec[18 + h] = R[9]; rec[20 + h] = R[10];                            // e2
+                    } else memcpy(&rec[6 + h], &padId, 4);
+                }
+                refs2.insert(refs2.end(), rec, rec + 24);
+            }
+            const uint32_t ref2 = 0x80000000u | (cnt << 27) | pair0;
+            memcpy(&nodes2[n * 16 + 12 + c], &ref2, 4);
+        }
+    }
+    if (refs2.empty()) refs2.resize(24, 0.f);
+}
+
 // include/mipt.h promises that no entry point throws: every body that can allocate on the host (vectors, strings,
 // the builder's worker threads) runs inside this guard.
 template <typename F> int guarded(mipt_tracer* t, F&& body) noexcept {
@@ -656,10 +694,19 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
             if (ok && d->envMap && d->envW && d->envH) ok = upload(&s->dEnv, d->envMap, (size_t)d->envW * d->envH * 3 * 4);
             if (ok && s->dEnv) ok = upload(&s->dEnvCdf, s->hEnvCdf.data(), s->hEnvCdf.size() * 4);
             if (ok && !s->hEmitCdf.empty()) ok = upload(&s->dEmitTri, s->hEmitTri.data(), s->hEmitTri.size() * 4) && upload(&s->dEmitCdf, s->hEmitCdf.data(), s->hEmitCdf.size() * 4);
+#ifdef MIPT_EXP_PAIR
+            if (ok) {
+                std::vector<float> nodes2, refs2;
+                build_pairs(s->hNodes, s->hRefs, s->bvhWidth, nodes2, refs2);
+                ok = upload(&s->dNodes2, nodes2.data(), nodes2.size() * 4) && upload(&s->dRefs2, refs2.data(), refs2.size() * 4);
+                s->nodes2Bytes = nodes2.size() * 4; s->refs2Bytes = refs2.size() * 4;
+            }
+#endif
             if (!ok) { mipt_scene_destroy(s); return fail(t, MIPT_E_NOMEM, "scene upload failed"); }
         }
         if (bo.refTri.empty()) s->hRefs.clear();
         s->dev.nodes = (const float4*)s->dNodes; s->dev.refs = (const float4*)s->dRefs; s->dev.shade = (const float4*)s->dShade;
+        s->dev.nodes2 = (const float4*)s->dNodes2; s->dev.refs2 = (const float4*)s->dRefs2;
         s->dev.mats = (const float4*)s->dMats; s->dev.env = (const float*)s->dEnv;
         s->dev.envW = s->dEnv ? d->envW : 0; s->dev.envH = s->dEnv ? d->envH : 0;
         s->dev.envCdf = (const float*)s->dEnvCdf;
@@ -683,6 +730,8 @@ void mipt_scene_destroy(mipt_scene* s) {
     if (s->t) hipSetDevice(s->t->device);
     if (s->dNodes) hipFree(s->dNodes);
     if (s->dRefs) hipFree(s->dRefs);
+    if (s->dNodes2) hipFree(s->dNodes2);
+    if (s->dRefs2) hipFree(s->dRefs2);
     if (s->dShade) hipFree(s->dShade);
     if (s->dMats) hipFree(s->dMats);
     if (s->dEnv) hipFree(s->dEnv);
@@ -717,6 +766,15 @@ int mipt_scene_refit(mipt_scene* s, const mipt_scene_desc* d) {
             HIPCHK(t, hipStreamSynchronize(t->stream));
             HIPCHK(t, hipMemcpy(s->dNodes, bo.nodes.data(), bo.nodes.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(t, hipMemcpy(s->dRefs, refs.data(), refs.size() * 4, hipMemcpyHostToDevice));
+#ifdef MIPT_EXP_PAIR
+            {   // the pair layout follows (same structure, so the same sizes)
+                std::vector<float> nodes2, refs2;
+                build_pairs(bo.nodes, refs, s->bvhWidth, nodes2, refs2);
+                if (nodes2.size() * 4 != s->nodes2Bytes || refs2.size() * 4 != s->refs2Bytes) return fail(t, MIPT_E_INVALID, "refit: pair layout changed size");
+                HIPCHK(t, hipMemcpy(s->dNodes2, nodes2.data(), nodes2.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(t, hipMemcpy(s->dRefs2, refs2.data(), refs2.size() * 4, hipMemcpyHostToDevice));
+            }
+#endif
             HIPCHK(t, hipMemcpy(s->dShade, shade.data(), shade.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(t, hipMemcpy(s->dMats, mats.data(), mats.size() * 4, hipMemcpyHostToDevice));
             const size_t nEmit = emitCdf.empty() ? 0 : emitCdf.size() - 1;

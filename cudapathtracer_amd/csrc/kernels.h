@@ -14,6 +14,13 @@ namespace mipt {
 struct SceneDev {
     const float4* nodes;
     const float4* refs;
+    // the same tree for k_wavestack when it walks the scene from L2 / HBM: reference records stored in PAIRS (96 B: the two
+    // triangles' components interleaved, v0x_a v0x_b v0y_a v0y_b | v0z_a v0z_b id_a id_b | e1x.. e1y.. | e1z_a e1z_b flags_a
+    // flags_b | e2x.. e2y.. | e2z_a e2z_b 0 0) so that one leaf-loop iteration tests two triangles with packed fp32
+    // arithmetic; every leaf starts a fresh pair (an odd leaf ends in a zero-area pad), and the leaf references of `nodes2`
+    // hold the PAIR index in their low 27 bits (count unchanged).  Built by api.hip build_pairs from nodes / refs.
+    const float4* nodes2;
+    const float4* refs2;
     const float4* shade;
     const float4* mats;
     const float*  env;        // float RGB rows, or nullptr

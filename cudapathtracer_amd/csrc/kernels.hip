@@ -82,6 +82,69 @@ MIPT_DEV bool mt_test(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, int id, int b
     return false;
 }
 
+// Two triangles per test with packed fp32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: each half is the IEEE
+// operation of the scalar form, so every value below equals what mt_test computes for that triangle, bit for bit).  The
+// pair comes interleaved from SceneDev::refs2, so that a loaded float4 holds (a, b) of two components in adjacent
+// registers; the ray's components are broadcast by the instruction's operand select.
+typedef float v2f __attribute__((ext_vector_type(2)));
+MIPT_DEV v2f pk(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+MIPT_DEV v2f pk1(float a) { v2f r; r.x = a; r.y = a; return r; }
+MIPT_DEV v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+struct v3p { v2f x, y, z; };
+MIPT_DEV v2f dot3p(const v3p& a, const v3p& b) { return pkfma(a.z, b.z, pkfma(a.y, b.y, a.x * b.x)); }
+MIPT_DEV v3p cross3p(const v3p& a, const v3p& b) {
+    v3p r;
+    r.x = pkfma(a.y, b.z, -(b.y * a.z)); r.y = pkfma(a.z, b.x, -(b.z * a.x)); r.z = pkfma(a.x, b.y, -(b.x * a.y));
+    return r;
+}
+struct PairTest { v2f det, t, u, v, uv; };
+#ifdef MIPT_EXP_PAIR_SCALAR
+// diagnostic: the same pair layout and loop, the arithmetic of the two halves as separate scalar instructions
+MIPT_DEV void mt_half(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float& det, float& t, float& u, float& v, float& uv) {
+    v3 pvec = cross3(d, e2);
+    det = dot3(e1, pvec);
+    const float inv = rcp_newton<1>(det);
+    v3 tvec = o - v0;
+    u = dot3(tvec, pvec) * inv;
+    v3 qvec = cross3(tvec, e1);
+    v = dot3(d, qvec) * inv;
+    t = dot3(e2, qvec) * inv;
+    uv = u + v;
+}
+MIPT_DEV PairTest mt_pair(v3 o, v3 d, const v3p& v0, const v3p& e1, const v3p& e2) {
+    PairTest r; float det, t, u, v, uv;
+    mt_half(o, d, mk3(v0.x.x, v0.y.x, v0.z.x), mk3(e1.x.x, e1.y.x, e1.z.x), mk3(e2.x.x, e2.y.x, e2.z.x), det, t, u, v, uv);
+    r.det.x = det; r.t.x = t; r.u.x = u; r.v.x = v; r.uv.x = uv;
+    mt_half(o, d, mk3(v0.x.y, v0.y.y, v0.z.y), mk3(e1.x.y, e1.y.y, e1.z.y), mk3(e2.x.y, e2.y.y, e2.z.y), det, t, u, v, uv);
+    r.det.y = det; r.t.y = t; r.u.y = u; r.v.y = v; r.uv.y = uv;
+    return r;
+}
+#else
+MIPT_DEV PairTest mt_pair(v3 o, v3 d, const v3p& v0, const v3p& e1, const v3p& e2) {
+    v3p D; D.x = pk1(d.x); D.y = pk1(d.y); D.z = pk1(d.z);
+    v3p pvec = cross3p(D, e2);
+    PairTest r;
+    r.det = dot3p(e1, pvec);
+    v2f inv = pk(__builtin_amdgcn_rcpf(r.det.x), __builtin_amdgcn_rcpf(r.det.y));       // rcp_newton<1>, the correction packed
+    const v2f e = pkfma(-r.det, inv, pk1(1.0f));
+    inv = pkfma(e, inv, inv);
+    v3p tvec; tvec.x = pk1(o.x) - v0.x; tvec.y = pk1(o.y) - v0.y; tvec.z = pk1(o.z) - v0.z;
+    r.u = dot3p(tvec, pvec) * inv;
+    v3p qvec = cross3p(tvec, e1);
+    r.v = dot3p(D, qvec) * inv;
+    r.t = dot3p(e2, qvec) * inv;
+    r.uv = r.u + r.v;
+    return r;
+}
+#endif
+// the accept / reject decisions of mt_test on one half of a PairTest (same comparisons, same NaN behaviour)
+// (one flat expression: in a wave some lane nearly always passes each early test, so branches only add mask bookkeeping)
+MIPT_DEV bool mt_accept(float det, float t, float u, float v, float uv, float tmin, int id, int bestId) {
+    const bool reject = (__builtin_fabsf(det) < FLT_EPSILON) | (u < 0) | (u > 1) | (v < 0) | (uv > 1);
+    const bool closer = (t > 0) & ((t < tmin) | ((t == tmin) & (id < bestId)));
+    return closer & !reject;
+}
+
 // Traversal stack: the first kLdsStack entries of every lane live in LDS (bank = lane, conflict-free), deeper
 // entries in a private scratch array that is only touched by unusually deep paths.  The stack pointer is a plain
 // register and the two halves are reached through separate branches: folding them into one struct/pointer select
@@ -703,6 +766,9 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
             uint32_t spix = 0, snode = 0, ss0 = 0;
             bool wantEnv = false, wantEmit = false, opaque = false;
             v3 sdir = mk3(0, 0, 1), scon = mk3(0, 0, 0), edir = mk3(0, 0, 1), econ = mk3(0, 0, 0); float etmax = 0.f;
+#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_CLASSCOUNT)
+            bool isRefr_ = false;
+#endif
             if (has) {
                 const uint32_t e = nF + lane;
                 v3 P = mk3(sq[0 * kSqCap + e], sq[1 * kSqCap + e], sq[2 * kSqCap + e]);
@@ -720,6 +786,9 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                 v3 hn = xyz(n0) * w0 + xyz(n1) * w1 + xyz(n2) * w2;
                 Surface sf; sf.P = P; sf.N = front ? hn : -hn; sf.mesh = __float_as_uint(n0.w);
                 Material mat = load_material(A.S, sf.mesh);
+#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_CLASSCOUNT)
+                isRefr_ = mat.opacity < 1.f;
+#endif
                 if (!(NEE && (fpix & kNoEmitBit))) add_sample(A.sample, spix, sb * (mat.emissive * mat.emissiveStrength));
                 Lcg rng; rng.state = node_seed(ss0, snode);
                 b = shade_hit<PBS>(mat, sf, sd, front, rng);
@@ -748,6 +817,12 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                     }
                 }
             }
+#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_CLASSCOUNT)
+            {   // shade batches that hold both material classes (-> stats[18]) and refractive records (-> stats[19]); they take the refill counters' slots
+                const unsigned long long hm_ = MIPT_BALLOT(has), rm_ = MIPT_BALLOT(isRefr_);
+                pf[10] += (rm_ != 0ull && rm_ != hm_) ? 1u : 0u; pf[11] += (uint32_t)__popcll(rm_);
+            }
+#endif
             const unsigned long long sm = NEE ? MIPT_BALLOT(wantEnv) : 0ull, em = NEE ? MIPT_BALLOT(wantEmit) : 0ull;
             const uint32_t nEnvRays = (uint32_t)__popcll(sm);
             // Hand-off: a lane without a ray keeps the second child of the record it has just shaded, so that child makes no
@@ -852,7 +927,9 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
             }
             sp -= take;
             refilled = take + got;
+#if !defined(MIPT_EXP_CLASSCOUNT)
             MIPT_PROF(pf[10]++; pf[11] += take + got;)
+#endif
             if (!active) {
                 const uint32_t rank = (uint32_t)__popcll(~actMask & below);
                 if (rank < got + take) {
@@ -916,7 +993,11 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
             if (go) {
                 MIPT_PROF(myNodes++;)
                 float4 n0, n1, n2, n3;
+#ifdef MIPT_EXP_PAIR
+                load_node<LDS_SCENE>(ldsNodes, A.S.nodes2, cur, n0, n1, n2, n3);       // (nodes2: leaf references count in pairs)
+#else
                 load_node<LDS_SCENE>(ldsNodes, A.S.nodes, cur, n0, n1, n2, n3);
+#endif
                 if constexpr (WIDE) {
                     // keep the four loads of the node together: without the child references in the hit test the
                     // compiler sinks their load behind it, a second dependent round trip per visit
@@ -966,7 +1047,35 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
         if (active) {
             if ((cur & kLeaf) && cur != kTerm) {
                 uint32_t cnt = (cur >> 27) & 0xFu, first = cur & 0x07FFFFFFu;
+#ifdef MIPT_EXP_PAIR
+                MIPT_PROF(myTris = LDS_SCENE ? cnt : (cnt + 1u) >> 1;)
+                // Measured and not adopted (profiles/r3/exp_pair_leaf.log): two triangles per leaf-loop iteration with packed
+                // fp32 arithmetic.  Bit-identical hits, 45 % fewer leaf-loop iterations and instructions, no gain.
+                if constexpr (!LDS_SCENE) {
+                    // two triangles per iteration from the pair layout (first = pair index; an odd leaf ends in a pad)
+                    for (uint32_t p = first; p < first + ((cnt + 1u) >> 1); p++) {
+                        const float4* T = A.S.refs2 + (size_t)p * 6;
+                        float4 q0 = T[0], q1 = T[1], q2 = T[2], q3 = T[3], q4 = T[4], q5 = T[5];
+                        asm volatile("" : "+v"(q0.x));        // all six loads of the record at once
+                        v3p v0, e1, e2;
+                        v0.x = pk(q0.x, q0.y); v0.y = pk(q0.z, q0.w); v0.z = pk(q1.x, q1.y);
+                        e1.x = pk(q2.x, q2.y); e1.y = pk(q2.z, q2.w); e1.z = pk(q3.x, q3.y);
+                        e2.x = pk(q4.x, q4.y); e2.y = pk(q4.z, q4.w); e2.z = pk(q5.x, q5.y);
+                        const PairTest r2 = mt_pair(o, d, v0, e1, e2);
+                        const int ida = (int)__float_as_uint(q1.z), idb = (int)__float_as_uint(q1.w);
+                        if (mt_accept(r2.det.x, r2.t.x, r2.u.x, r2.v.x, r2.uv.x, h.t, ida, h.tri)) {
+                            h.t = r2.t.x; h.v = r2.v.x; h.front = r2.det.x > 0; h.tri = ida;
+                            h.u = __uint_as_float(__float_as_uint(r2.u.x) | (__float_as_uint(q3.z) << 30));     // flags bit 1 -> sign bit
+                        }
+                        if (mt_accept(r2.det.y, r2.t.y, r2.u.y, r2.v.y, r2.uv.y, h.t, idb, h.tri)) {
+                            h.t = r2.t.y; h.v = r2.v.y; h.front = r2.det.y > 0; h.tri = idb;
+                            h.u = __uint_as_float(__float_as_uint(r2.u.y) | (__float_as_uint(q3.w) << 30));
+                        }
+                    }
+                } else
+#else
                 MIPT_PROF(myTris = cnt;)
+#endif
                 for (uint32_t i = first; i < first + cnt; i++) {
                     float4 a, b, c;
                     load_ref<LDS_SCENE>(ldsRefs, A.S.refs, i, a, b, c);

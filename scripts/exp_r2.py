@@ -41,7 +41,7 @@ for spec in args:
     res = {}
     for w in workloads:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", str(steps), "--warmup", "3", "--cpu-seconds", "0",
-               "--min-seconds", str(minsec)] + opts + extra
+               "--min-seconds", str(minsec), "--trace-loop-frames", "0"] + opts + extra
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
