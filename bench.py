@@ -314,7 +314,7 @@ def run_workload(name, a, ctx, cpu_seconds):
         nn, nr = len(nodes), len(refs)
         launches_total = n_rep * a.steps
         if a.integrator == 0:    # one k_wavestack launch per frame traces every ray of the frame
-            lds = sc.bvh_width == 2 and nn * 4 + nr * 3 <= 256          # <LDS scene, 4-wide nodes, light sampling, estimator-2 lobes>
+            lds = sc.bvh_width == 2 and nn * 4 + nr * 3 <= 192          # <LDS scene, 4-wide nodes, light sampling, estimator-2 lobes>
             kernel_name = "mipt::k_wavestack<%s, %s, %s, %s>" % tuple("true" if x else "false" for x in (lds, sc.bvh_width == 4, a.estimator in (1, 3), a.estimator >= 2))
             sec_rays, sec_ms, sec_launches = float(cnt.rays), prof.ms[0], prof.launches[0]
         else:                    # k_level<false,*> launches carry the non-primary levels

@@ -48,7 +48,7 @@ struct BvhOut {
 };
 
 constexpr uint32_t kMaxBvhDepth = 64;       // traversal stack capacity on the device
-constexpr uint32_t kLdsSceneFloat4 = 256;   // float4 slots of the kernels' LDS scene window (kernels.hip kLdsSceneVec)
+constexpr uint32_t kLdsSceneFloat4 = 192;   // float4 slots of the kernels' LDS scene window (kernels.hip kLdsSceneVec)
 constexpr uint32_t kMaxWideStack = 96;      // traversal stack capacity of the 4-wide kernels
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kEmptyRef = 0x80000000u; // 4-wide nodes: "no child" (a leaf of zero references)

@@ -467,7 +467,7 @@ MIPT_DEV void add_sample(float* sample, uint32_t pix, v3 c) {
 // =================================================================================================================
 // Wavefront level kernel.  Persistent grid-stride over the input queue; every lane handles one ray per iteration.
 // =================================================================================================================
-constexpr uint32_t kLdsSceneVec = 256;     // float4 slots (4 KiB) for an LDS-resident scene (the Cornell box needs 168)
+constexpr uint32_t kLdsSceneVec = 192;     // float4 slots (3 KiB) for an LDS-resident scene (the Cornell box needs 168); with the 9-entry stack a 256-thread block takes exactly 40 KiB
 
 template <bool PRIMARY, bool LDS_SCENE>
 __global__ void __launch_bounds__(kBlock) k_level(LevelArgs A) {
@@ -585,7 +585,7 @@ void launch_level(const LevelArgs& a, bool primary, int blocks, hipStream_t s) {
 MIPT_DEV uint32_t band_pixel(const Band& b, uint32_t local) { return ((local / b.pixels) * b.stride + b.first) * b.pixels + local % b.pixels; }
 // LDS-resident scenes are tiny trees: 8 LDS stack entries cover them (the host checks stackNeed), which leaves their
 // blocks the same 112-entry queue next to the 4 KiB scene window (96 entries with a 12-entry stack: 1 % slower on Cornell)
-constexpr int kLdsSceneStack = 8;
+constexpr int kLdsSceneStack = 8;       // the builder's bound an LDS-resident scene must meet; the array has one spare entry on top (see the BVH2 visit)
 template <bool LDS_SCENE> struct SqCap { static constexpr int value = 112; };
 constexpr int kSqWords = 16;         // dwords per entry, SoA by dword: conflict-free LDS access
 
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
     constexpr int kStackStride = kBlock;
     constexpr int kSqCap = SqCap<LDS_SCENE>::value;
     constexpr bool kShortRcp = true;       // 3-instruction reciprocals for the rays this kernel generates itself (ray_pre, mt_test): +2-3 %
-    __shared__ uint32_t ldsStack[(LDS_SCENE ? kLdsSceneStack : kLdsStack) * kBlock];
+    __shared__ uint32_t ldsStack[(LDS_SCENE ? kLdsSceneStack + 1 : kLdsStack) * kBlock];
     __shared__ float sqMem[(kBlock / 64) * kSqWords * kSqCap];
     __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneVec : 1];
     if (LDS_SCENE) {
@@ -1002,8 +1002,29 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                     // keep the four loads of the node together: without the child references in the hit test the
                     // compiler sinks their load behind it, a second dependent round trip per visit
                     asm volatile("" : "+v"(n3.w));
+#ifndef MIPT_EXP_BRANCHY_VISIT
+                    // The entry a miss would pop is fetched now, beside the node: its LDS latency hides behind the node's,
+                    // and what follows the visit needs no branch -- push and pop are one rule.  While the three slots above
+                    // the top are inside the LDS part of the stack (tsp <= kLdsStack - 3, all but unusually deep paths) they
+                    // are written unconditionally: slot j gets s[nh-1-j] (farthest deepest, second-nearest on top), what
+                    // lands above the new top is never read, and with no child hit the new top is one lower and the next
+                    // node is the entry fetched here.
+                    const bool shallow = tsp <= kLdsStack - 3;
+                    uint32_t popped = kTerm;
+                    if (shallow) popped = lstk[(tsp - 1) * kBlock];        // (tsp >= 1: the sentinel is never popped by a visit)
+#endif
                     uint32_t s0_, s1_, s2_, s3_;
                     const int nh = wide_visit(r, n0, n1, n2, n3, h.t, s0_, s1_, s2_, s3_);
+#ifndef MIPT_EXP_BRANCHY_VISIT
+                    if (shallow) {
+                        const uint32_t a0 = nh == 4 ? s3_ : (nh == 3 ? s2_ : s1_);
+                        const uint32_t a1 = nh == 4 ? s2_ : s1_;
+                        uint32_t* const top = lstk + tsp * kBlock;
+                        top[0] = a0; top[kBlock] = a1; top[2 * kBlock] = s1_;
+                        tsp += nh - 1;
+                        cur = nh ? s0_ : popped;
+                    } else
+#endif
                     if (nh == 0) { MIPT_STACK_POP(lstk, deep, tsp, cur); }
                     else {
                         if (tsp <= kLdsStack - 3) {
@@ -1024,9 +1045,21 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                     }
                 } else {
                     float t0, t1;
+                    uint32_t popped = kTerm;
+                    if constexpr (LDS_SCENE) popped = lstk[(tsp - 1) * kBlock];       // what a miss pops, fetched beside the node
                     bool h0 = slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, h.t, t0);
                     bool h1 = slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, h.t, t1);
                     uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
+                    if constexpr (LDS_SCENE) {
+                        // push and pop as one branch-free rule (the LDS stack has one spare entry above the builder's bound, so
+                        // the unconditional store never leaves it): the far child goes above the top, and is kept only when
+                        // both children are hit; with no child hit the next node is the entry fetched above
+                        const bool both = h0 & h1, any = h0 | h1, swap = both & (t1 < t0);
+                        const uint32_t first = (h0 & !swap) ? c0 : c1, second = swap ? c0 : c1;
+                        lstk[tsp * kBlock] = second;
+                        tsp += both ? 1 : (any ? 0 : -1);
+                        cur = any ? first : popped;
+                    } else
                     if (h0 || h1) {
                         uint32_t first = h0 ? c0 : c1;
                         if (h0 && h1) {
@@ -1081,13 +1114,28 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                     load_ref<LDS_SCENE>(ldsRefs, A.S.refs, i, a, b, c);
                     // all three loads of the record at once (the compiler sinks the vertex behind the determinant test)
                     if constexpr (!LDS_SCENE) asm volatile("" : "+v"(a.x));
-                    float tt, uu, vv; bool ff;
                     int id = (int)__float_as_uint(a.w);
-                    if (mt_test<kShortRcp>(o, d, xyz(a), xyz(b), xyz(c), h.t, id, h.tri, tt, uu, vv, ff)) {
-                        h.t = tt; h.u = uu; h.v = vv; h.front = ff; h.ref = (int)i; h.tri = id;
-                        h.u = __uint_as_float(__float_as_uint(uu) | (__float_as_uint(c.w) << 30));     // flags bit 1 -> sign bit
+                    // mt_test without its early returns: the same values and the same decisions as one flat expression.  In a
+                    // wave some lane nearly always passes each of the early tests, so the returns skipped nothing and cost a
+                    // nest of exec-mask branches (~40 scalar instructions per test): Cornell +6.1 %, Default +4.6 %, grid +2.6 %
+                    // (profiles/r3/exp_flat_leaf.log)
+                    {
+                        const v3 v0_ = xyz(a), e1_ = xyz(b), e2_ = xyz(c);
+                        const v3 pvec = cross3(d, e2_);
+                        const float det = dot3(e1_, pvec);
+                        const float inv = rcp_newton<1>(det);
+                        const v3 tvec = o - v0_;
+                        const float uu = dot3(tvec, pvec) * inv;
+                        const v3 qvec = cross3(tvec, e1_);
+                        const float vv = dot3(d, qvec) * inv;
+                        const float tt = dot3(e2_, qvec) * inv;
+                        if (mt_accept(det, tt, uu, vv, uu + vv, h.t, id, h.tri)) {
+                            h.t = tt; h.v = vv; h.front = det > 0; h.tri = id;
+                            h.u = __uint_as_float(__float_as_uint(uu) | (__float_as_uint(c.w) << 30));     // flags bit 1 -> sign bit
+                        }
                     }
                 }
+                // (fetching the popped entry ahead of the triangles, as the node visits do, measured -0.5 % here: exp_flat_visit.log)
                 if constexpr (LDS_SCENE) MIPT_STACK_POP_L(lstk, tsp, cur); else MIPT_STACK_POP(lstk, deep, tsp, cur);
                 if constexpr (NEE) if ((pix & kShadowBit) && h.tri >= 0) cur = kTerm;      // occlusion ray: any hit ends it
                 // no emitting mesh in the scene: a last-level ray adds nothing if it hits anything, so its first hit ends it

@@ -54,7 +54,7 @@ typedef struct {
     uint32_t nodeWidth;                                 /* 2 = fp32 BVH2 nodes; 4 = the BVH2 collapsed to 4 children per node with
                                                            child boxes quantised to 8 bits per plane (still 64 B per node, about
                                                            half the node visits); 0 = auto: 2 if the scene fits the kernels'
-                                                           4 KiB LDS window (e.g. the Cornell box), else 4 */
+                                                           3 KiB LDS window (e.g. the Cornell box), else 4 */
     const char* bvhCachePath;                           /* NULL, or a file: if it holds the BVH of exactly these triangles and
                                                            build parameters it is loaded (structure re-validated) instead of
                                                            building; otherwise the BVH is built and written there.  No
