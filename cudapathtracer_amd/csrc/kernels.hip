@@ -927,7 +927,7 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
             }
             sp -= take;
             refilled = take + got;
-#if !defined(MIPT_EXP_CLASSCOUNT)
+#if !defined(MIPT_EXP_CLASSCOUNT) && !defined(MIPT_EXP_NH0COUNT)
             MIPT_PROF(pf[10]++; pf[11] += take + got;)
 #endif
             if (!active) {
@@ -972,6 +972,9 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
 
         // ---- D. one traversal round: descend to the next leaf, test it, park the rays that have terminated ----------
         MIPT_PROF(uint32_t myNodes = 0; uint32_t myTris = 0;)
+#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_NH0COUNT)
+        uint32_t myNh0 = 0, myNh1 = 0;
+#endif
         // The node loop is wave-uniform: every lane stays in it and the visit runs under `go`.  It ends when fewer than
         // minDescend lanes are still at inner nodes -- those resume next round, after the others' leaves have been
         // tested and terminated rays replaced -- which bounds the tail of the loop (profiles/r1/lane_profile_*.log).
@@ -1015,6 +1018,9 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
 #endif
                     uint32_t s0_, s1_, s2_, s3_;
                     const int nh = wide_visit(r, n0, n1, n2, n3, h.t, s0_, s1_, s2_, s3_);
+#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_NH0COUNT)
+                    myNh0 += nh == 0 ? 1u : 0u; myNh1 += nh == 1 ? 1u : 0u;      // (take the refill counters' slots: stats[18], stats[19])
+#endif
 #ifndef MIPT_EXP_BRANCHY_VISIT
                     if (shallow) {
                         const uint32_t a0 = nh == 4 ? s3_ : (nh == 3 ? s2_ : s1_);
@@ -1151,6 +1157,9 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
         } while (again);
         MIPT_PROF(pf[0]++; pf[1] += (uint32_t)__popcll(MIPT_BALLOT(active)); pf[2] += wave_max_u32(myNodes); pf[3] += wave_sum_u32(myNodes);
                   pf[4] += wave_max_u32(myTris); pf[5] += wave_sum_u32(myTris);)
+#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_NH0COUNT)
+        pf[10] += wave_sum_u32(myNh0); pf[11] += wave_sum_u32(myNh1);
+#endif
         bool fin = active && cur == kTerm;
         unsigned long long fm = MIPT_BALLOT(fin);
         // the one state a stalled wave cannot leave by itself (see A1): no lane refilled, none still traversing, and -- checked
