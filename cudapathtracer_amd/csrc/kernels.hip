@@ -1060,11 +1060,13 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                         // push and pop as one branch-free rule (the LDS stack has one spare entry above the builder's bound, so
                         // the unconditional store never leaves it): the far child goes above the top, and is kept only when
                         // both children are hit; with no child hit the next node is the entry fetched above
-                        const bool both = h0 & h1, any = h0 | h1, swap = both & (t1 < t0);
-                        const uint32_t first = (h0 & !swap) ? c0 : c1, second = swap ? c0 : c1;
+                        // (written so that the decisions stay lane masks in scalar registers: no 0/1 values in VGPRs)
+                        const bool nearIs1 = h1 & (!h0 | (t1 < t0));
+                        const uint32_t first = nearIs1 ? c1 : c0, second = nearIs1 ? c0 : c1;
                         lstk[tsp * kBlock] = second;
-                        tsp += both ? 1 : (any ? 0 : -1);
-                        cur = any ? first : popped;
+                        tsp = (tsp - 1) + ((h0 && h1) ? 1 : 0);          // two add-with-carry on the lane masks
+                        tsp += (h0 || h1) ? 1 : 0;
+                        cur = (h0 || h1) ? first : popped;
                     } else
                     if (h0 || h1) {
                         uint32_t first = h0 ? c0 : c1;
