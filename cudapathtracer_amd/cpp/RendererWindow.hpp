@@ -4,6 +4,7 @@
 #pragma once
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <memory>
 #include <string>
 #include <vector>
@@ -110,6 +111,55 @@ public:
         std::fclose(f);
         return true;
     }
+    // Checkpoint / resume.  The accumulation buffer, the sample index and the camera are the whole state of a progressive
+    // render (CUDATracerProg.cu:878,895-897: frame k folds with weight 1/(k+1), frame 0 overwrites); the reference keeps it
+    // only in the window's lifetime.  A checkpoint is a 64-byte header + the RGBA32F accumulation, bottom-up as in memory.
+    struct CheckpointHeader {
+        char magic[8]; std::uint32_t version, width, height, frameID, maxDepth; CameraParams cam; std::uint32_t pad[3];
+    };
+    static_assert(sizeof(CheckpointHeader) == 64, "checkpoint header is 64 bytes");
+    bool SaveCheckpoint(const std::string& path) {
+        if (!accBuffer) return false;
+        CheckpointHeader h{};
+        std::memcpy(h.magic, "MIPTCKP", 8); h.version = 1;
+        h.width = (std::uint32_t)bitmapSize.x; h.height = (std::uint32_t)bitmapSize.y;
+        h.frameID = renderSettings->Get<0>().frameID; h.maxDepth = renderSettings->Get<0>().maxDepth; h.cam = camParam;
+        const float* a = accumulation();                   // blocking read-back: every frame traced so far is in it
+        const std::string tmp = path + ".tmp";             // written beside the target and renamed: never a half-written checkpoint
+        FILE* f = std::fopen(tmp.c_str(), "wb");
+        if (!f) return false;
+        const size_t n = (size_t)h.width * h.height * 4;
+        bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(a, sizeof(float), n, f) == n;
+        ok = (std::fclose(f) == 0) && ok;
+        if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) { std::remove(tmp.c_str()); return false; }
+        return true;
+    }
+    // Resumes from a checkpoint: buffers of the stored size, the stored camera, depth and sample index; the next render()
+    // traces sample `frameID` and folds it with weight 1 / (frameID + 1), exactly as if the run had never stopped.
+    // False (and nothing changed) when the file is missing, damaged, truncated, or of another version.
+    bool LoadCheckpoint(const std::string& path) {
+        FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f) return false;
+        CheckpointHeader h{};
+        bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "MIPTCKP", 8) == 0 && h.version == 1
+                  && h.width >= 1 && h.height >= 1 && h.width <= 16384 && h.height <= 16384 && h.maxDepth >= 1 && h.maxDepth <= 64;
+        std::vector<float> acc;
+        if (ok) {
+            const size_t n = (size_t)h.width * h.height * 4;
+            acc.resize(n);
+            ok = std::fread(acc.data(), sizeof(float), n, f) == n && std::fgetc(f) == EOF;
+        }
+        std::fclose(f);
+        if (!ok) return false;
+        resize({ (int)h.width, (int)h.height });
+        std::memcpy(accBuffer->mutable_cpu_data(), acc.data(), acc.size() * sizeof(float));     // uploaded with the next Trace
+        camParam = h.cam;
+        auto& settings = renderSettings->GetMutable<0>();
+        settings.frameID = h.frameID; settings.maxDepth = h.maxDepth;
+        UpdateCam(settings.cam);
+        return true;
+    }
+
     bool WritePFM(const std::string& path) {             // PFM is bottom-up like the buffers
         const float* a = accumulation();
         FILE* f = std::fopen(path.c_str(), "wb");

@@ -362,6 +362,78 @@ def test_renderer_window_input_resets_accumulation_and_preview_files(tmp_path):
     assert not os.path.exists(f"{prefix}_5.ppm")
 
 
+CHECKPOINT_MAIN = r"""
+// checkpoint / resume of a progressive render: 6 frames in one go against 3 frames, checkpoint, a NEW window, 3 more frames
+#include <cstdio>
+#include <cmath>
+#include "RendererWindow.hpp"
+using namespace CUDATracer;
+struct Wnd : RendererWindow {
+    using RendererWindow::RendererWindow;
+    const PathTraceSettings& st() { return renderSettings->Get<0>(); }
+    void depth(unsigned d) { renderSettings->GetMutable<0>().maxDepth = d; }
+};
+#define EXPECT(c) do { if (!(c)) { std::printf("FAILED line %d: %s\n", __LINE__, #c); return 1; } } while (0)
+int main(int argc, char** argv) {
+    try {
+        const std::string ck = argv[1];
+        const int W = 48, H = 32;
+        std::vector<float> whole;
+        {
+            Wnd w(Scenes::CornellBox(), "t", W, H);
+            w.camParam = Scenes::CornellCamera(); w.camParam.azimuth += 0.05f;
+            w.resize({ W, H }); w.depth(5);
+            for (int f = 0; f < 6; f++) { w.Update(); w.render(); }
+            whole.assign(w.accumulation(), w.accumulation() + (size_t)W * H * 4);
+        }
+        {
+            Wnd w(Scenes::CornellBox(), "t", W, H);
+            w.camParam = Scenes::CornellCamera(); w.camParam.azimuth += 0.05f;
+            w.resize({ W, H }); w.depth(5);
+            for (int f = 0; f < 3; f++) { w.Update(); w.render(); }
+            EXPECT(w.SaveCheckpoint(ck));
+        }
+        Wnd r(Scenes::CornellBox(), "t", 8, 8);                      // another size, another camera, another depth: all restored
+        EXPECT(!r.LoadCheckpoint(ck + ".missing"));
+        EXPECT(r.LoadCheckpoint(ck));
+        EXPECT(r.frameID() == 3 && r.st().viewportWidth == W && r.st().viewportHeight == H && r.st().maxDepth == 5);
+        for (int f = 0; f < 3; f++) { r.Update(); r.render(); }
+        EXPECT(r.frameID() == 6);
+        const float* a = r.accumulation();
+        double num = 0, den = 0; float worst = 0;
+        for (size_t i = 0; i < whole.size(); i++) { num += std::fabs(a[i] - whole[i]); den += std::fabs(whole[i]); worst = std::fmax(worst, std::fabs(a[i] - whole[i]) / (1e-3f + std::fabs(whole[i]))); }
+        std::printf("resumed vs uninterrupted: mean rel %.3g worst %.3g\n", num / den, worst);
+        EXPECT(den > 0 && num / den < 1e-6 && worst < 2e-5f);        // only the order of the adds into a pixel differs
+        // a damaged or truncated file is refused and changes nothing
+        FILE* f = std::fopen(ck.c_str(), "rb"); std::vector<unsigned char> bytes((size_t)64 + (size_t)W * H * 16); EXPECT(std::fread(bytes.data(), 1, bytes.size(), f) == bytes.size()); std::fclose(f);
+        auto put = [&](const std::string& p, size_t n) { FILE* g = std::fopen(p.c_str(), "wb"); std::fwrite(bytes.data(), 1, n, g); std::fclose(g); };
+        put(ck + ".short", bytes.size() - 5);
+        EXPECT(!r.LoadCheckpoint(ck + ".short") && r.frameID() == 6);
+        bytes[0] ^= 1; put(ck + ".magic", bytes.size());
+        EXPECT(!r.LoadCheckpoint(ck + ".magic") && r.frameID() == 6);
+        std::printf("OK\n");
+    } catch (const std::exception& e) { std::printf("error: %s\n", e.what()); return 1; }
+    return 0;
+}
+"""
+
+
+@pytest.mark.gpu
+def test_renderer_window_checkpoint_and_resume(tmp_path):
+    """SURVEY §5 (checkpoint / resume, optional): accumulation + sample index + camera saved by one window and resumed by
+    another give the image of the uninterrupted run (same samples; only the order of the atomic adds differs)."""
+    src = tmp_path / "ck.cpp"
+    src.write_text(CHECKPOINT_MAIN)
+    exe = str(tmp_path / "ck")
+    libdir = os.path.join(ROOT, "cudapathtracer_amd")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(libdir, "cpp"), str(src), "-o", exe, "-L", libdir, "-lmipt",
+                        "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe, str(tmp_path / "render.ckpt")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert os.path.getsize(tmp_path / "render.ckpt") == 64 + 48 * 32 * 16 and not os.path.exists(tmp_path / "render.ckpt.tmp")
+
+
 @pytest.mark.gpu
 def test_objscene_app_loads_builds_caches_and_renders(tmp_path):
     # a 64x64 height-field written as OBJ quads (8 k triangles), rendered twice: second run takes the BVH from the cache
