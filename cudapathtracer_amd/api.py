@@ -77,7 +77,7 @@ class LevelProfile(C.Structure):
 HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("tri", "<i4"), ("mesh", "<i4"), ("front", "<i4")])
 VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("uv", "<f4", 2)])
 
-BVH_SBVH, BVH_MEDIAN = 0, 1
+BVH_SBVH, BVH_MEDIAN, BVH_LBVH_GPU = 0, 1, 2
 RNG_NODE, RNG_DFS = 0, 1
 
 _vp = C.c_void_p

@@ -6,6 +6,7 @@
 // and CUDABuffer (CUDATracer/CUDABuffer.cpp:111-224).
 #include "../../include/mipt.h"
 #include "bvh_builder.h"
+#include "gpu_bvh.h"
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -652,7 +653,8 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
         if (int rc = gather_geometry(t, d, tris, triMesh, shade)) return rc;
         BvhParams bp;
         bp.builder = d->bvhBuilder;
-        if (bp.builder != MIPT_BVH_SBVH && bp.builder != MIPT_BVH_MEDIAN) return fail(t, MIPT_E_INVALID, "unknown bvhBuilder");
+        if (bp.builder != MIPT_BVH_SBVH && bp.builder != MIPT_BVH_MEDIAN && bp.builder != MIPT_BVH_LBVH_GPU) return fail(t, MIPT_E_INVALID, "unknown bvhBuilder");
+        if (bp.builder == MIPT_BVH_LBVH_GPU && !t) return fail(t, MIPT_E_INVALID, "bvhBuilder MIPT_BVH_LBVH_GPU needs a tracer (a GPU to build on)");
         if (d->maxLeafSize) bp.maxLeafSize = d->maxLeafSize;
         if (d->splitAlpha > 0.f) bp.splitAlpha = d->splitAlpha;
         // SAH triangle cost: measured optima are 1.5 for a scene traversed as BVH2 from LDS (a few dozen triangles) and 3.0
@@ -666,7 +668,17 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
         const bool cached = useCache && load_bvh_cache(d->bvhCachePath, cacheKey, (uint32_t)tris.size(), bp.nodeWidth, bo);
         if (!cached) {
             bo = BvhOut();
-            std::string berr = build_bvh(tris, bp, bo);
+            std::string berr;
+            if (bp.builder == MIPT_BVH_LBVH_GPU) {
+                // built on the device, then held to the same structural check as a cache file before any kernel walks it:
+                // every index in range, one tree rooted at node 0, every triangle referenced, stack bound (sets stackNeed)
+                GpuBuildTimes gt;
+                berr = build_bvh_gpu(tris, bp, bo, t->stream, &gt);
+                if (berr.empty()) berr = validate_bvh(bo, (uint32_t)tris.size());
+                if (berr.empty() && std::getenv("MIPT_BUILD_VERBOSE"))
+                    fprintf(stderr, "[mipt] GPU BVH build: %zu triangles -> %zu %s nodes; upload %.1f ms, codes + sort %.1f, tree + boxes + BVH2 %.1f, 4-wide collapse %.1f, download %.1f\n",
+                            tris.size(), bo.nodes.size() / 16, bo.width == 4 ? "4-wide" : "BVH2", gt.uploadMs, gt.sortMs, gt.treeMs, gt.collapseMs, gt.downloadMs);
+            } else berr = build_bvh(tris, bp, bo);
             if (!berr.empty()) return fail(t, MIPT_E_LIMIT, "BVH build: " + berr);
             if (useCache && !save_bvh_cache(d->bvhCachePath, cacheKey, (uint32_t)tris.size(), bo))
                 return fail(t, MIPT_E_INVALID, std::string("cannot write BVH cache ") + d->bvhCachePath);

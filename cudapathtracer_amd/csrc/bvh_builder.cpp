@@ -24,6 +24,7 @@
 // node / reference indices rebased.  Whether a subtree is built by a child depends only on its reference count, and
 // the big sorts are chunk-sort + merge under a strict total order, so the tree is identical for every thread count.
 #include "bvh_builder.h"
+#include "bvh_quantise.h"
 
 #include <algorithm>
 #include <atomic>
@@ -440,49 +441,6 @@ private:
 // ---- BVH2 -> quantised 4-wide nodes ------------------------------------------------------------------------------
 struct WideChild { uint32_t ref; Box b; };
 
-// writes one 4-wide node at P (16 floats) from up to four child boxes; false when an extent cannot be represented
-inline float scale_of(uint32_t e) { uint32_t b = e << 23; float f; memcpy(&f, &b, 4); return f; }
-bool quantise_node(float* P, const WideChild* ch, int n, const uint32_t* refs) {
-    bool failed = false;
-    Box nb; for (int i = 0; i < n; i++) if (ch[i].b.valid()) nb.grow(ch[i].b);
-    if (!nb.valid()) for (int a = 0; a < 3; a++) nb.mn[a] = nb.mx[a] = 0.f;
-    uint32_t e[3]; uint8_t qlo[3][4], qhi[3][4];
-    // a slot without a child gets an inverted box (entry plane behind the exit plane on every axis): the slab test
-    // rejects it by itself (and should rounding ever let it through, its reference is a leaf of zero triangles)
-    memset(qlo, 255, sizeof(qlo)); memset(qhi, 0, sizeof(qhi));
-    for (int a = 0; a < 3; a++) {
-        const float origin = nb.mn[a];
-        // smallest power of two with 255 * scale >= extent; kept inside [2^-60, 2^40] so the product with a ray's
-        // inverse direction (1 <= |idir| <= 2^80) stays a normal, finite number
-        int ex = 127 - 60;
-        const float ext = nb.mx[a] - origin;
-        while (ex < 167 && 255.0f * scale_of((uint32_t)ex) < ext) ex++;
-        for (;; ex++) {      // widen until every child plane fits (fp32 rounding of the extent can cost one step)
-            bool ok = true;
-            const float sc = scale_of((uint32_t)ex);
-            for (int i = 0; i < n && ok; i++) {
-                if (!ch[i].b.valid()) { qlo[a][i] = 255; qhi[a][i] = 0; continue; }
-                int lo = (int)std::floor((ch[i].b.mn[a] - origin) / sc); lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
-                while (lo > 0 && std::fma((float)lo, sc, origin) > ch[i].b.mn[a]) lo--;
-                int hi = (int)std::ceil((ch[i].b.mx[a] - origin) / sc); hi = hi < 0 ? 0 : hi;
-                while (hi <= 255 && std::fma((float)hi, sc, origin) < ch[i].b.mx[a]) hi++;
-                if (hi > 255 || std::fma((float)lo, sc, origin) > ch[i].b.mn[a]) { ok = false; break; }
-                qlo[a][i] = (uint8_t)lo; qhi[a][i] = (uint8_t)hi;
-            }
-            if (ok) break;
-            if (ex >= 167) { failed = true; break; }     // extent beyond 2^48: not representable
-        }
-        e[a] = (uint32_t)ex;
-    }
-    memcpy(P, nb.mn, 12);
-    // the per-axis scales as floats (powers of two): a visit multiplies them straight into the ray's inverse direction
-    P[3] = scale_of(e[2]);
-    for (int a = 0; a < 3; a++) { memcpy(P + 4 + a, qlo[a], 4); memcpy(P + 7 + a, qhi[a], 4); }
-    P[10] = scale_of(e[0]); P[11] = scale_of(e[1]);
-    memcpy(P + 12, refs, 16);
-    return !failed;
-}
-
 class Collapser {
 public:
     Collapser(const std::vector<float>& n2, std::vector<float>& n4) : N2(n2), N4(n4) {}
@@ -528,7 +486,9 @@ private:
     const std::vector<float>& N2; std::vector<float>& N4;
 
     void quantise(uint32_t self, const WideChild* ch, int n, const uint32_t* refs) {
-        if (!quantise_node(&N4[(size_t)self * 16], ch, n, refs)) failed = true;
+        QBox qb[4];
+        for (int i = 0; i < n; i++) { memcpy(qb[i].mn, ch[i].b.mn, 12); memcpy(qb[i].mx, ch[i].b.mx, 12); }
+        if (!quantise_node(&N4[(size_t)self * 16], qb, n, refs)) failed = true;      // bvh_quantise.h, shared with the GPU builder
     }
 };
 
@@ -709,7 +669,9 @@ std::string refit_bvh(BvhOut& out, const std::vector<TriPos>& tris) {
             if (ch[c].b.valid()) nodeBox[n].grow(ch[c].b);
         }
         if (wide) {
-            if (!quantise_node(P, ch, 4, r)) return "scene extent too large for quantised 4-wide nodes";
+            QBox qb[4];
+            for (int c = 0; c < 4; c++) { memcpy(qb[c].mn, ch[c].b.mn, 12); memcpy(qb[c].mx, ch[c].b.mx, 12); }
+            if (!quantise_node(P, qb, 4, r)) return "scene extent too large for quantised 4-wide nodes";
         } else {
             // a zero-reference leaf (the builder's root padding) has no box of its own: it takes its sibling's
             for (int c = 0; c < 2; c++) {

@@ -41,7 +41,11 @@ typedef struct {
 } mipt_mesh_desc;
 
 enum { MIPT_BVH_SBVH = 0,     /* spatial-split BVH (algorithm of CUDATracer/SplitBVHBuilder.cpp:57-512) */
-       MIPT_BVH_MEDIAN = 1 }; /* median split, leaf <= 4, depth <= 32 (CUDATracer/Types.hpp:312-413), one tree for the scene */
+       MIPT_BVH_MEDIAN = 1,   /* median split, leaf <= 4, depth <= 32 (CUDATracer/Types.hpp:312-413), one tree for the scene */
+       MIPT_BVH_LBVH_GPU = 2 };/* built on the tracer's GPU (no counterpart in the reference, which builds on the host): Morton codes, radix sort,
+                                  Karras' radix tree, boxes bottom-up, leaves of <= maxLeafSize triangles, the same 4-wide collapse and quantisation
+                                  as the host builders; checked on the host (every index, the stack bound) before it is used.  Needs a tracer and
+                                  >= 64 triangles; a few times faster to build and slower to trace than the SBVH: for scenes that are rebuilt often */
 
 typedef struct {
     const mipt_mesh_desc* meshes; uint32_t meshCnt;     /* Scene::objects       Types.hpp:427-433 */
