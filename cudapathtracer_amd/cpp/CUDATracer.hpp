@@ -57,8 +57,11 @@ struct SceneInfoHeader {               // [header | MeshInfoHeader*[meshCnt]]
 class CUDAScene {
 public:
     // bvhCachePath: optional BVH cache file (mipt_scene_desc::bvhCachePath); $MIPT_BVH_CACHE is used when it is null
-    explicit CUDAScene(const Scene& scn, unsigned bvhBuilder = MIPT_BVH_SBVH, const char* bvhCachePath = nullptr) {
+    // bvhBuilder: MIPT_BVH_*; left at its default it is $MIPT_BVH_BUILDER (0 SBVH, 1 median, 2 built on the GPU), else the SBVH
+    static constexpr unsigned kBuilderFromEnv = ~0u;
+    explicit CUDAScene(const Scene& scn, unsigned bvhBuilder = kBuilderFromEnv, const char* bvhCachePath = nullptr) {
         std::vector<mipt_mesh_desc> meshes; mipt_scene_desc d = Describe(scn, meshes);
+        if (bvhBuilder == kBuilderFromEnv) { const char* e = std::getenv("MIPT_BVH_BUILDER"); bvhBuilder = e && e[0] ? (unsigned)std::atoi(e) : (unsigned)MIPT_BVH_SBVH; }
         d.bvhBuilder = bvhBuilder;
         d.bvhCachePath = bvhCachePath ? bvhCachePath : std::getenv("MIPT_BVH_CACHE");
         detail::Check(mipt_scene_create(detail::DefaultTracer(), &d, &_s), "mipt_scene_create");

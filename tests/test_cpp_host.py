@@ -460,6 +460,14 @@ def test_objscene_app_loads_builds_caches_and_renders(tmp_path):
     hdr = b"PF\n96 64\n-1.0\n"
     a, b = (np.frombuffer(o[len(hdr):], np.float32) for o in outs)
     assert np.allclose(a, b, rtol=1e-4, atol=1e-6) and a.mean() > 0.01      # same BVH -> same image (up to add order)
+    # the same app with the tree built on the GPU ($MIPT_BVH_BUILDER=2 -> CUDAScene): closest hits do not depend on the tree,
+    # so neither does the image
+    pfm = str(tmp_path / "gpu.pfm")
+    r = subprocess.run([os.path.join(APPS, "objscene"), str(tmp_path / "hf.obj"), "96", "64", "4", str(tmp_path / "gpu.ppm"), pfm],
+                       capture_output=True, text=True, timeout=180, env=dict(os.environ, MIPT_BVH_BUILDER="2", MIPT_BUILD_VERBOSE="1"))
+    assert r.returncode == 0 and "GPU BVH build: 8194 triangles" in r.stderr          # the height field + the app's ground quad, r.stdout + r.stderr
+    g = np.frombuffer(open(pfm, "rb").read()[len(hdr):], np.float32)
+    assert np.allclose(a, g, rtol=1e-4, atol=1e-6)
 
 
 PLY_MAIN = r"""
