@@ -49,6 +49,35 @@ def test_gpu_built_tree_gives_the_oracles_closest_hits(tracer, ptlib, oracle, sc
     assert hits_equal(g, r) <= 3
 
 
+@pytest.mark.parametrize("n,max_leaf,width", [(64, 4, 4), (65, 1, 2), (1000, 15, 4), (777, 2, 2), (4097, 1, 4), (300, 8, 0)])
+def test_gpu_build_edge_sizes_and_leaf_sizes(tracer, ptlib, oracle, n, max_leaf, width):
+    """the smallest scene the builder takes, odd counts, one triangle per leaf and the largest leaves; also coordinates far from
+    the origin and a scene squeezed into a sliver (Morton cells are cubes of the largest extent: two axes collapse to one cell)"""
+    from conftest import triangle_soup
+    for shape in ("soup", "far", "sliver"):
+        v, i = triangle_soup(n, n)
+        if shape == "far":
+            v["position"] += np.float32(3.0e5)
+        elif shape == "sliver":
+            v["position"][:, 1:] *= np.float32(1e-4)
+        data = ptlib.SceneData([(v, i, ptlib.make_material())], soup_scene(1, 1).sky)
+        sc = ptlib.Scene(tracer, data, builder=ptlib.BVH_LBVH_GPU, max_leaf=max_leaf, node_width=width)
+        nodes, refs, w = sc.flat()
+        assert len(refs) == n
+        o = oracle.Scene(data)
+        o.set_flat_bvh(nodes, refs, w)
+        assert o.check_flat_bvh() == (0, ""), shape
+        og, dg = random_rays(60000, 3)
+        if shape == "far":
+            og += np.float32(3.0e5)
+        elif shape == "sliver":
+            og[:, 1:] *= np.float32(1e-4); dg[:, 0] *= np.float32(1e-3); dg /= np.linalg.norm(dg, axis=1, keepdims=True)
+        g = tracer.trace_rays(sc, og, dg)
+        c, _ = o.trace_rays(oracle.ISECT_FLAT, og, dg, nthreads=16)
+        assert hits_equal(g, c) == 0, shape
+        assert (c["tri"] >= 0).sum() > 50, shape
+
+
 def test_gpu_build_is_deterministic_and_refuses_what_it_cannot_do(tracer, ptlib):
     data = soup_scene(50000, 11)
     a = ptlib.Scene(tracer, data, builder=ptlib.BVH_LBVH_GPU).flat()
