@@ -86,7 +86,7 @@ def parse():
     return p.parse_args()
 
 
-def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0):
+def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0, emit_tree=None):
     """Times the CPU oracle (same flat BVH, node-keyed RNG) on a bounded sample of the workload and returns its rate and
     the mean node visits / triangle tests per ray (the figures the algorithmic bytes and operations are computed from)."""
     from oracle import orc                      # cpu_baseline leg only: checker / reported baseline
@@ -95,20 +95,22 @@ def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0)
     o.set_flat_bvh(*bvh, width)
     o.set_estimator(estimator)
     o.set_anyhit_last_level(True)       # count the work of the product's algorithm (last-level rays need only hit-or-miss)
+    if emit_tree and emit_tree[0]:      # ... and in a scene with emitters they go through the emitters' tree first
+        o.set_emitter_tree(*emit_tree)
     W, H = settings.viewportWidth, settings.viewportHeight
 
     def run(rows, depth):
         s = pt.Settings()
         C.memmove(C.addressof(s), C.addressof(settings), C.sizeof(pt.Settings))
         s.maxDepth = depth
-        tot = dict(rays=0, nodes=0, tris=0, hits=0, anyhit=0, sec=0.0)
+        tot = dict(rays=0, nodes=0, tris=0, hits=0, anyhit=0, emitfirst=0, sec=0.0)
         acc = np.zeros((H, W, 4), np.float32)
         for y in rows:      # bands of BAND rows: enough 64-pixel work items per call to keep 16 threads busy
             t0 = time.perf_counter()
             r = o.render(s, orc.ISECT_FLAT, orc.RNG_NODE, orc.MATH_DET, 0, 1, rect=(0, y, W, min(y + BAND, H)), acc=acc, want_ldr=False, nthreads=threads)
             tot["sec"] += time.perf_counter() - t0
             st = r["stats"]
-            tot["rays"] += st.rays; tot["nodes"] += st.node_visits; tot["tris"] += st.tri_tests; tot["hits"] += st.hits; tot["anyhit"] += st.anyhit_rays
+            tot["rays"] += st.rays; tot["nodes"] += st.node_visits; tot["tris"] += st.tri_tests; tot["hits"] += st.hits; tot["anyhit"] += st.anyhit_rays; tot["emitfirst"] += st.emitfirst_rays
         return tot
 
     BAND = 8
@@ -124,7 +126,7 @@ def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0)
         t0 = time.perf_counter()
         r = o.render(s, orc.ISECT_FLAT, orc.RNG_NODE, orc.MATH_DET, 0, n_frames, want_ldr=False, nthreads=threads)
         st = r["stats"]
-        full = dict(rays=st.rays, nodes=st.node_visits, tris=st.tri_tests, hits=st.hits, anyhit=st.anyhit_rays, sec=time.perf_counter() - t0)
+        full = dict(rays=st.rays, nodes=st.node_visits, tris=st.tri_tests, hits=st.hits, anyhit=st.anyhit_rays, emitfirst=st.emitfirst_rays, sec=time.perf_counter() - t0)
         desc = f"frames 0..{n_frames - 1} of the same workload, whole"
     else:
         n_bands = max(1, n_rows // BAND)
@@ -133,7 +135,7 @@ def oracle_sample(pt, data, bvh, width, settings, seconds, threads, estimator=0)
         desc = f"{len(rows)} evenly spaced bands of {BAND} rows of frame 0 of the same workload"
     rays = max(full["rays"], 1)
     return dict(desc=desc, rays=full["rays"], sec=full["sec"], mrays=full["rays"] / full["sec"] / 1e6,
-                n_node=full["nodes"] / rays, n_tri=full["tris"] / rays, miss=1.0 - full["hits"] / rays, anyhit=full["anyhit"] / rays)
+                n_node=full["nodes"] / rays, n_tri=full["tris"] / rays, miss=1.0 - full["hits"] / rays, anyhit=full["anyhit"] / rays, emitfirst=full["emitfirst"] / rays)
 
 
 def dbg(msg):
@@ -311,11 +313,13 @@ def run_workload(name, a, ctx, cpu_seconds):
     out = None
     if rank == 0:
         nodes, refs = sc.bvh()
-        nn, nr = len(nodes), len(refs)
+        e_nodes, e_refs, _ = sc.emitter_tree()            # behind the main tree on the device (scenes with emitters)
+        nn, nr = len(nodes) + len(e_nodes), len(refs) + len(e_refs)
         launches_total = n_rep * a.steps
         if a.integrator == 0:    # one k_wavestack launch per frame traces every ray of the frame
             lds = sc.bvh_width == 2 and nn * 4 + nr * 3 <= 192          # <LDS scene, 4-wide nodes, light sampling, estimator-2 lobes>
-            kernel_name = "mipt::k_wavestack<%s, %s, %s, %s>" % tuple("true" if x else "false" for x in (lds, sc.bvh_width == 4, a.estimator in (1, 3), a.estimator >= 2))
+            emit_variant = bool(sc.emitter_tree()[2]) and a.estimator in (0, 2)      # <..., EMIT>: the scene has an emitters' tree
+            kernel_name = "mipt::k_wavestack<%s, %s, %s, %s, %s>" % tuple("true" if x else "false" for x in (lds, sc.bvh_width == 4, a.estimator in (1, 3), a.estimator >= 2, emit_variant))
             sec_rays, sec_ms, sec_launches = float(cnt.rays), prof.ms[0], prof.launches[0]
         else:                    # k_level<false,*> launches carry the non-primary levels
             kernel_name = "mipt::k_level<false,*>"
@@ -325,7 +329,9 @@ def run_workload(name, a, ctx, cpu_seconds):
         cpu = None
         if cpu_seconds > 0:
             threads = min(os.cpu_count() or 1, 16)
-            cpu = oracle_sample(pt, data, (nodes, refs), sc.bvh_width, settings, cpu_seconds if world == 1 else min(cpu_seconds, 3.0), threads, a.estimator)
+            # the oracle walks the arrays the device holds: the main tree and, behind it, the emitters' tree (if the scene has one)
+            fn, fr, _, eroot, nmain = sc.flat_with_emitters()
+            cpu = oracle_sample(pt, data, (fn, fr), sc.bvh_width, settings, cpu_seconds if world == 1 else min(cpu_seconds, 3.0), threads, a.estimator, (eroot, nmain))
         default_config = (W, H, depth) == WORKLOADS[name][1:] and (name != "grid" or a.grid_n == 2236) and not a.node_width and not a.tri_cost and not a.max_leaf and not a.estimator and not a.option and a.integrator == 0 and a.pipeline == 1
         pmc, pmc_label = pmc_for(name, default_config)
         working_set = nn * 64 + nr * 48
@@ -406,6 +412,10 @@ def run_workload(name, a, ctx, cpu_seconds):
             # share of the counted rays that are last-level rays traced hit-or-miss (scenes without emitting meshes: such a
             # ray adds nothing if it hits anything, so it stops at its first hit; same image, cheaper ray), from the CPU sample
             "anyhit_ray_frac": None if cpu is None else round(cpu["anyhit"], 4),
+            # share of the counted rays that are last-level rays in a scene WITH emitters: intersected with the emitting triangles
+            # first, then walked through the scene only as far as it takes to know whether that emitter is the closest hit (same
+            # image; a ray that can add nothing costs two triangle tests on the Cornell box)
+            "emitter_first_ray_frac": None if cpu is None else round(cpu["emitfirst"], 4),
             "accumulate_ms": round(prof.accumulate_ms / max(launches_total, 1), 3),
             "roofline": roof,
         }

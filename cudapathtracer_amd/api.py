@@ -101,6 +101,7 @@ lib.mipt_scene_get_bvh.argtypes = [_vp, _vp, C.POINTER(C.c_uint32), _vp, C.POINT
 lib.mipt_scene_triangle_count.argtypes = [_vp]
 lib.mipt_scene_triangle_count.restype = C.c_uint32
 lib.mipt_scene_bvh_was_cached.argtypes = [_vp]
+lib.mipt_scene_get_emitter_tree.argtypes = [_vp, _vp, C.POINTER(C.c_uint32), _vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
 lib.mipt_scene_get_env_cdf.argtypes = [_vp, _vp, C.c_uint64]
 lib.mipt_scene_get_env_cdf.restype = C.c_uint64
 lib.mipt_scene_get_emitters.argtypes = [_vp, _vp, _vp, C.c_uint64]
@@ -331,6 +332,25 @@ class Scene:
         """(nodes, refs, width): what the oracle's set_flat_bvh takes."""
         nodes, refs = self.bvh()
         return nodes, refs, self.bvh_width
+
+    def emitter_tree(self):
+        """(nodes, refs, root_ref) of the emitters' tree as it lies behind the main tree on the device; root_ref 0: none"""
+        nn, nr, root = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        lib.mipt_scene_get_emitter_tree(self.h, None, C.byref(nn), None, C.byref(nr), C.byref(root))
+        nodes = np.zeros((nn.value, 16), np.float32)
+        refs = np.zeros((nr.value, 12), np.float32)
+        if root.value:
+            lib.mipt_scene_get_emitter_tree(self.h, _ptr(nodes) if nn.value else None, C.byref(nn), _ptr(refs), C.byref(nr), C.byref(root))
+        return nodes, refs, root.value
+
+    def flat_with_emitters(self):
+        """(nodes, refs, width, root_ref, n_refs_main): the device's arrays -- main tree, then the emitters' tree -- for the
+        oracle's set_flat_bvh + set_emitter_tree"""
+        nodes, refs = self.bvh()
+        en, er, root = self.emitter_tree()
+        if not root:
+            return nodes, refs, self.bvh_width, 0, len(refs)
+        return np.concatenate([nodes, en]), np.concatenate([refs, er]), self.bvh_width, root, len(refs)
 
     def close(self):
         if self.h:

@@ -101,6 +101,11 @@ struct mipt_scene {
     std::vector<float> hEmitTri, hEmitCdf;      // estimator 1: emissive triangles (15 floats each) and their area CDF
     std::vector<float> hNodes, hRefs;    // host copies for mipt_scene_get_bvh
     std::vector<uint32_t> hRefTri;       // triangle id per reference (mipt_scene_refit)
+    // "emitters first" (kernels.h SceneDev::emitRoot): a second tree over the emitting triangles alone, appended to the device's
+    // node / reference arrays behind the main tree.  Host side: the tree with its own indices, the triangles it is built over
+    // (global ids), its reference records; on the device: room for emitNodeCap nodes and emitRefCap references behind the main tree
+    BvhOut hEmitBvh; std::vector<uint32_t> hEmitIds; std::vector<float> hEmitNodes, hEmitRefs; uint32_t emitRootRef = 0, emitNodeCap = 0, emitRefCap = 0, mainStackNeed = 0;
+    BvhParams bvhParams;                         // what the scene was built with (the emitters' tree is rebuilt with it when materials change)
     uint32_t nMeshes = 0; size_t emitCap = 0;   // emitCap: emissive triangles the device buffers hold
     uint32_t nTris = 0;
     uint32_t bvhWidth = 2;
@@ -394,6 +399,64 @@ void fill_refs(const mipt_scene_desc* d, const std::vector<uint32_t>& refTri, co
         memcpy(&R[3], &g, 4); memcpy(&R[7], &triMesh[g], 4); memcpy(&R[11], &flags, 4);
     }
 }
+// ---- the emitters' tree ("emitters first", kernels.h SceneDev::emitRoot) ---------------------------------------------------------
+// Built over the triangles of emitting meshes: up to 15 of them are one leaf (no node at all), more get a tree of their own from
+// the host builder in the main tree's node layout.  Returns false -- no emitters' tree, the kernels trace last-level rays as before --
+// when nothing or everything emits, or when the tree would not fit what the main tree fits (traversal stack, LDS window).
+struct EmitTree { BvhOut bvh; std::vector<uint32_t> ids; uint32_t stackNeed = 0; };
+bool make_emit_tree(const mipt_scene_desc* d, const std::vector<TriPos>& tris, const std::vector<uint32_t>& triMesh, const BvhParams& bpMain,
+                    uint32_t mainWidth, uint32_t mainNodes, uint32_t mainRefs, uint32_t mainStackNeed, EmitTree& et) {
+    et = EmitTree();
+#ifdef MIPT_EXP_PAIR
+    return false;       // (the pair-layout experiment keeps one tree)
+#endif
+    if (const char* e = std::getenv("MIPT_EMITTER_TREE")) if (e[0] == '0') return false;
+    for (uint32_t g = 0; g < (uint32_t)tris.size(); g++) if (mesh_emits(d->meshes[triMesh[g]].material)) et.ids.push_back(g);
+    if (et.ids.empty() || et.ids.size() == tris.size()) return false;
+    if (et.ids.size() <= 15) {
+        et.bvh.refTri.resize(et.ids.size());
+        for (uint32_t i = 0; i < (uint32_t)et.ids.size(); i++) et.bvh.refTri[i] = i;
+        et.bvh.width = mainWidth;
+        et.stackNeed = 2;                                    // the sentinel and the main root
+    } else {
+        std::vector<TriPos> sub(et.ids.size());
+        for (size_t i = 0; i < et.ids.size(); i++) sub[i] = tris[et.ids[i]];
+        BvhParams bp = bpMain;
+        bp.builder = bpMain.builder == MIPT_BVH_MEDIAN ? MIPT_BVH_MEDIAN : MIPT_BVH_SBVH;     // (host builders; the set is small)
+        bp.nodeWidth = mainWidth;
+        if (!build_bvh(sub, bp, et.bvh).empty() || et.bvh.width != mainWidth) return false;
+        et.stackNeed = et.bvh.stackNeed + 1;                 // + the main root waiting below
+    }
+    const bool wide = mainWidth == 4;
+    if (et.stackNeed > (wide ? kMaxWideStack : kMaxBvhDepth)) return false;
+    // a main tree that is traversed from LDS stays there: both trees must fit the window and the 8-entry LDS stack
+    const bool mainInLds = !wide && mainNodes * 4 + mainRefs * 3 <= kLdsSceneFloat4 && mainStackNeed <= 8;
+    if (mainInLds) {
+        const size_t all = (size_t)(mainNodes + et.bvh.nodes.size() / 16) * 4 + (size_t)(mainRefs + et.bvh.refTri.size()) * 3;
+        if (all > kLdsSceneFloat4 || et.stackNeed > 8) return false;
+    }
+    if ((uint64_t)mainRefs + et.bvh.refTri.size() >= (1u << 27)) return false;
+    return true;
+}
+// the emitters' tree as it lies behind the main tree: node indices and leaf ranges moved up, references as global triangle ids
+uint32_t place_emit_tree(const EmitTree& et, const mipt_scene_desc* d, const std::vector<TriPos>& tris, const std::vector<uint32_t>& triMesh,
+                         uint32_t mainNodes, uint32_t mainRefs, std::vector<float>& nodes, std::vector<float>& refs) {
+    nodes = et.bvh.nodes;
+    const int fan = et.bvh.width == 4 ? 4 : 2;
+    for (size_t n = 0; n < nodes.size() / 16; n++) {
+        uint32_t r[4]; memcpy(r, &nodes[n * 16 + 12], 16);
+        for (int c = 0; c < fan; c++) {
+            if (!(r[c] & kLeafFlag)) r[c] += mainNodes;
+            else if ((r[c] >> 27) & 0xFu) r[c] = make_leaf_ref((r[c] & 0x07FFFFFFu) + mainRefs, (r[c] >> 27) & 0xFu);     // (empty slots stay kEmptyRef)
+        }
+        memcpy(&nodes[n * 16 + 12], r, 16);
+    }
+    std::vector<uint32_t> refTri(et.bvh.refTri.size());
+    for (size_t i = 0; i < refTri.size(); i++) refTri[i] = et.ids[et.bvh.refTri[i]];
+    fill_refs(d, refTri, tris, triMesh, refs);
+    return nodes.empty() ? make_leaf_ref(mainRefs, (uint32_t)refTri.size()) : mainNodes;
+}
+
 void fill_materials(const mipt_scene_desc* d, std::vector<float>& mats) {
     mats.assign((size_t)std::max<uint32_t>(d->meshCnt, 1) * 12, 0.f);
     for (uint32_t m = 0; m < d->meshCnt; m++) {
@@ -699,9 +762,30 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
             return true;
         };
         if (shade.empty()) shade.resize(12, 0.f);
+        const uint32_t mainNodes = (uint32_t)(s->hNodes.size() / 16), mainRefs = (uint32_t)bo.refTri.size();
+        s->mainStackNeed = bo.stackNeed; s->bvhParams = bp;
+        std::vector<float> emitNodes;
+        {
+            EmitTree et;
+            if (make_emit_tree(d, tris, triMesh, bp, bo.width, mainNodes, mainRefs, bo.stackNeed, et)) {
+                s->emitRootRef = place_emit_tree(et, d, tris, triMesh, mainNodes, mainRefs, emitNodes, s->hEmitRefs);
+                s->hEmitBvh = std::move(et.bvh); s->hEmitIds = std::move(et.ids);
+                bo.stackNeed = std::max(bo.stackNeed, et.stackNeed);
+            }
+        }
+        s->emitNodeCap = (uint32_t)(emitNodes.size() / 16); s->emitRefCap = (uint32_t)(s->hEmitRefs.size() / 12);
+        s->hEmitNodes = emitNodes;
         if (s->hRefs.empty()) s->hRefs.resize(12, 0.f);
         if (t) {
-            bool ok = upload(&s->dNodes, s->hNodes.data(), s->hNodes.size() * 4) && upload(&s->dRefs, s->hRefs.data(), s->hRefs.size() * 4) &&
+            // nodes and references as the kernels see them: the main tree, then the emitters' tree
+            std::vector<float> nodesAll, refsAll;
+            const std::vector<float>* upNodes = &s->hNodes; const std::vector<float>* upRefs = &s->hRefs;
+            if (s->emitRootRef) {
+                nodesAll = s->hNodes; nodesAll.insert(nodesAll.end(), emitNodes.begin(), emitNodes.end());
+                refsAll.assign(s->hRefs.begin(), s->hRefs.begin() + (size_t)mainRefs * 12); refsAll.insert(refsAll.end(), s->hEmitRefs.begin(), s->hEmitRefs.end());
+                upNodes = &nodesAll; upRefs = &refsAll;
+            }
+            bool ok = upload(&s->dNodes, upNodes->data(), upNodes->size() * 4) && upload(&s->dRefs, upRefs->data(), upRefs->size() * 4) &&
                       upload(&s->dShade, shade.data(), shade.size() * 4) && upload(&s->dMats, mats.data(), mats.size() * 4);
             if (ok && d->envMap && d->envW && d->envH) ok = upload(&s->dEnv, d->envMap, (size_t)d->envW * d->envH * 3 * 4);
             if (ok && s->dEnv) ok = upload(&s->dEnvCdf, s->hEnvCdf.data(), s->hEnvCdf.size() * 4);
@@ -727,7 +811,8 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
         s->emitCap = s->dev.nEmit;
         s->dev.neeScale = s->dEnv ? (float)(M_PI / 0.98 / ((double)d->envW * (double)d->envH)) : 0.f;
         memcpy(s->dev.skyColor, d->sky.color, 12); memcpy(s->dev.skyDir, d->sky.dir, 12); s->dev.skyIntensity = d->sky.intensity;
-        s->dev.nNodes = (uint32_t)(s->hNodes.size() / 16); s->dev.nRefs = (uint32_t)bo.refTri.size();
+        s->dev.nNodes = mainNodes + s->emitNodeCap; s->dev.nRefs = mainRefs + s->emitRefCap;
+        s->dev.emitRoot = s->emitRootRef; s->dev.nRefsMain = mainRefs;
         s->dev.wide = bo.width == 4 ? 1u : 0u;
         s->dev.stackNeed = bo.stackNeed;
         s->dev.emissiveMeshes = count_emissive_meshes(d);
@@ -773,11 +858,37 @@ int mipt_scene_refit(mipt_scene* s, const mipt_scene_desc* d) {
         fill_refs(d, s->hRefTri, tris, triMesh, refs);
         fill_materials(d, mats);
         const float emitScale = build_emitters(d, tris, triMesh, emitTri, emitCdf);
+        // the emitters' tree: the same emitting triangles -> same shape, boxes re-fitted; another set (a material edit) -> rebuilt
+        // if it fits the room behind the main tree, else the scene goes on without one
+        const uint32_t mainNodes = (uint32_t)(bo.nodes.size() / 16), mainRefs = (uint32_t)s->hRefTri.size();
+        EmitTree et; std::vector<float> emitNodes, emitRefs; uint32_t emitRoot = 0;
+        {
+            std::vector<uint32_t> ids;
+            for (uint32_t g = 0; g < (uint32_t)tris.size(); g++) if (mesh_emits(d->meshes[triMesh[g]].material)) ids.push_back(g);
+            bool have = false;
+            if (!s->hEmitIds.empty() && ids == s->hEmitIds) {      // (also when an edit in between had switched the tree off: its shape is kept)
+                et.bvh = s->hEmitBvh; et.ids = ids; have = true;
+                if (!et.bvh.nodes.empty()) {
+                    std::vector<TriPos> sub(ids.size());
+                    for (size_t i = 0; i < ids.size(); i++) sub[i] = tris[ids[i]];
+                    have = refit_bvh(et.bvh, sub).empty();
+                }
+                et.stackNeed = et.bvh.nodes.empty() ? 2u : et.bvh.stackNeed + 1u;
+            } else if (s->emitRefCap) {
+                have = make_emit_tree(d, tris, triMesh, s->bvhParams, s->bvhWidth, mainNodes, mainRefs, s->mainStackNeed, et) &&
+                       et.bvh.nodes.size() / 16 <= s->emitNodeCap && et.bvh.refTri.size() <= s->emitRefCap;
+            }
+            if (have) emitRoot = place_emit_tree(et, d, tris, triMesh, mainNodes, mainRefs, emitNodes, emitRefs);
+        }
         if (t) {
             // every frame in flight has been joined by use(); the stream of this tracer may still be running them
             HIPCHK(t, hipStreamSynchronize(t->stream));
             HIPCHK(t, hipMemcpy(s->dNodes, bo.nodes.data(), bo.nodes.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(t, hipMemcpy(s->dRefs, refs.data(), refs.size() * 4, hipMemcpyHostToDevice));
+            if (emitRoot) {
+                if (!emitNodes.empty()) HIPCHK(t, hipMemcpy((char*)s->dNodes + (size_t)mainNodes * 64, emitNodes.data(), emitNodes.size() * 4, hipMemcpyHostToDevice));
+                HIPCHK(t, hipMemcpy((char*)s->dRefs + (size_t)mainRefs * 48, emitRefs.data(), emitRefs.size() * 4, hipMemcpyHostToDevice));
+            }
 #ifdef MIPT_EXP_PAIR
             {   // the pair layout follows (same structure, so the same sizes)
                 std::vector<float> nodes2, refs2;
@@ -806,6 +917,9 @@ int mipt_scene_refit(mipt_scene* s, const mipt_scene_desc* d) {
             s->dev.nEmit = (uint32_t)nEmit; s->dev.emitScale = emitScale;
         }
         s->dev.emissiveMeshes = count_emissive_meshes(d);
+        s->dev.emitRoot = s->emitRootRef = emitRoot;
+        s->dev.stackNeed = emitRoot ? std::max(s->mainStackNeed, et.stackNeed) : s->mainStackNeed;
+        if (emitRoot) { s->hEmitBvh = std::move(et.bvh); s->hEmitIds = std::move(et.ids); s->hEmitRefs.swap(emitRefs); s->hEmitNodes.swap(emitNodes); }
         // the analytic sky is a launch parameter, not a buffer: taken from the desc as well (the env map stays)
         memcpy(s->dev.skyColor, d->sky.color, 12); memcpy(s->dev.skyDir, d->sky.dir, 12); s->dev.skyIntensity = d->sky.intensity;
         s->hNodes.swap(bo.nodes); s->hRefs.swap(refs); s->hEmitTri.swap(emitTri); s->hEmitCdf.swap(emitCdf);
@@ -820,6 +934,18 @@ int mipt_scene_get_bvh(const mipt_scene* s, float* nodes, uint32_t* n_nodes, flo
         if (n_refs) *n_refs = (uint32_t)(s->hRefs.size() / 12);
         if (nodes) memcpy(nodes, s->hNodes.data(), s->hNodes.size() * 4);
         if (refs) memcpy(refs, s->hRefs.data(), s->hRefs.size() * 4);
+        return MIPT_OK;
+    });
+}
+int mipt_scene_get_emitter_tree(const mipt_scene* s, float* nodes, uint32_t* n_nodes, float* refs, uint32_t* n_refs, uint32_t* root_ref) {
+    return guarded(nullptr, [&]() -> int {
+        if (!s) return MIPT_E_INVALID;
+        const bool on = s->emitRootRef != 0;
+        if (n_nodes) *n_nodes = on ? (uint32_t)(s->hEmitNodes.size() / 16) : 0u;
+        if (n_refs) *n_refs = on ? (uint32_t)(s->hEmitRefs.size() / 12) : 0u;
+        if (root_ref) *root_ref = s->emitRootRef;
+        if (on && nodes && !s->hEmitNodes.empty()) memcpy(nodes, s->hEmitNodes.data(), s->hEmitNodes.size() * 4);
+        if (on && refs) memcpy(refs, s->hEmitRefs.data(), s->hEmitRefs.size() * 4);
         return MIPT_OK;
     });
 }

@@ -36,6 +36,10 @@ struct SceneDev {
     uint32_t nEmit; float emitScale;   // total emissive area / (2 pi 0.98)
     uint32_t emissiveMeshes;  // meshes whose hits can add emission (strength != 0 and a non-black colour); 0: a hit at the last
                               // level adds nothing, whichever triangle it is, so those rays only need to know hit-or-miss
+    // Emitters first (scenes with emitting meshes): behind the main tree's nodes and references sits a second, small tree over
+    // the emitting triangles alone.  emitRoot = its root reference (an inner node index >= the main tree's node count, or a
+    // leaf reference when the emitters fit one leaf); 0 = none.  References from nRefsMain on belong to it.  (k_wavestack, D)
+    uint32_t emitRoot, nRefsMain;
 };
 
 // Per-frame constants computed once on the host (CUDATracerProg.cu:369-397 computes them per thread).

@@ -144,6 +144,19 @@ MIPT_DEV bool mt_accept(float det, float t, float u, float v, float uv, float tm
     const bool closer = (t > 0) & ((t < tmin) | ((t == tmin) & (id < bestId)));
     return closer & !reject;
 }
+// does the ray hit the triangle of a reference record at all (t > 0)?  The leaf loop's arithmetic and acceptance, with no bound
+MIPT_DEV bool mt_hits(v3 o, v3 d, float4 a, float4 b, float4 c) {
+    const v3 v0_ = xyz(a), e1_ = xyz(b), e2_ = xyz(c);
+    const v3 pvec = cross3(d, e2_);
+    const float det = dot3(e1_, pvec);
+    const float inv = rcp_newton<1>(det);
+    const v3 tvec = o - v0_;
+    const float uu = dot3(tvec, pvec) * inv;
+    const v3 qvec = cross3(tvec, e1_);
+    const float vv = dot3(d, qvec) * inv;
+    const float tt = dot3(e2_, qvec) * inv;
+    return mt_accept(det, tt, uu, vv, uu + vv, __builtin_inff(), 0, -1);
+}
 
 // Traversal stack: the first kLdsStack entries of every lane live in LDS (bank = lane, conflict-free), deeper
 // entries in a private scratch array that is only touched by unusually deep paths.  The stack pointer is a plain
@@ -681,7 +694,7 @@ MIPT_DEV uint32_t wave_sum_u32(uint32_t v) { for (int s = 32; s > 0; s >>= 1) v 
 template <bool LDS_SCENE> struct WaveStackBlock { static constexpr int value = LDS_SCENE ? 256 : 64; };
 // 4 waves per SIMD at the 128-VGPR cap (4-5 spills outside the hot loops).  Three with the ~145 VGPRs the compiler would
 // like (no spills) run 0.85x; five at 96 VGPRs and 32 KiB of LDS per 256 threads spill 35-40 registers, 0.6-0.7x.
-template <bool LDS_SCENE, bool WIDE, bool NEE, bool PBS = false>
+template <bool LDS_SCENE, bool WIDE, bool NEE, bool PBS = false, bool EMIT = false>      // EMIT: the scene has an emitters' tree ("emitters first", below)
 __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavestack(StackArgs A) {       // (hipcc: second argument = minimum waves per SIMD)
     constexpr int kBlock = WaveStackBlock<LDS_SCENE>::value;       // shadows the file-wide block size inside this kernel
     constexpr int kStackStride = kBlock;
@@ -736,6 +749,14 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
     //  * in a scene without emitting meshes a last-level ray only needs hit-or-miss: it stops at its first triangle hit.
     // (the "emits" flag of the closest triangle so far rides in the sign bit of h.u -- u >= 0 -- so it costs no register)
     const bool skyBlack = A.S.env == nullptr && A.S.skyIntensity == 0.f;
+    // Emitters first.  A last-level ray can only add emission (or the sky, if it escapes): what it needs is "is the closest hit an
+    // emitter", not the closest hit.  In a scene with emitting meshes it therefore walks the small tree of the emitting
+    // triangles first (SceneDev::emitRoot) -- the main tree's root waits on its stack -- and then the main tree with the
+    // distance found as its bound, where the first hit on anything that does not emit ends it (it is occluded, or there was no
+    // emitter to begin with); under a black sky a ray that found no emitter never enters the main tree at all.  Same image:
+    // an emitter that is the closest hit is still found and not occluded, every other outcome adds nothing either way.  The
+    // oracle restates it as a counting option (orc_scene_set_emitter_tree), so the roofline counts the work of this algorithm.
+    constexpr bool emitFirst = EMIT && !NEE;       // (a template flag: scenes without such a tree run the code they ran before)
 
     while (true) {
         const unsigned long long actMask = MIPT_BALLOT(active);
@@ -829,6 +850,63 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
             // trip through the wave stack (throughput unchanged; HBM traffic per Cornell frame 8.6 -> 4.9 GB, most of it
             // write-backs of stack lines that were dead by the time they were evicted: profiles/r2/exp_handoff.log).
             // Not for the light-sampling variants, which are short of registers as it is.
+            if constexpr (emitFirst) {
+                // Emitters first, one step earlier.  Children that will be at the last level, under a black sky, in a scene whose
+                // emitters fit one leaf: such a child can only add something if it hits one of those few triangles, so it is
+                // tested against them here, with the leaf loop's own arithmetic, and a child that hits none of them is counted
+                // as traced and never written to the wave stack (it would be popped, run this very test in its first round and
+                // be retired).  A child that does hit an emitter goes the usual way.
+                bool keep1 = has, keep2 = has;
+                if (skyBlack && (A.S.emitRoot & kLeaf)) {                      // wave-uniform
+                    const bool kidsLast = has && (32u - (uint32_t)__clz((int)(snode * 2u))) >= A.F.maxDepth;
+                    if (MIPT_BALLOT(kidsLast)) {
+                        bool hit1 = false, hit2 = false;
+                        const uint32_t efirst = A.S.emitRoot & 0x07FFFFFFu, ecnt = (A.S.emitRoot >> 27) & 0xFu;
+                        for (uint32_t i = efirst; i < efirst + ecnt; i++) {
+                            float4 ta, tb, tc;
+                            load_ref<LDS_SCENE>(ldsRefs, A.S.refs, i, ta, tb, tc);
+                            hit1 |= mt_hits(b.o1, b.d1, ta, tb, tc);
+                            hit2 |= mt_hits(b.o2, b.d2, ta, tb, tc);
+                        }
+                        if (kidsLast) {
+                            keep1 = hit1; keep2 = hit2;
+                            const uint32_t gone = (hit1 ? 0u : 1u) + (hit2 ? 0u : 1u);
+                            traced += gone;
+                            if (A.pixelRays && gone) atomicAdd(A.pixelRays + spix, gone);
+                        }
+                    }
+                }
+                const bool takeOwn = keep2 && !active;
+                const bool push2 = keep2 && !takeOwn;
+                const unsigned long long k1 = MIPT_BALLOT(keep1), k2 = MIPT_BALLOT(push2);
+                const uint32_t w = sp + (uint32_t)__popcll(k1 & below) + (uint32_t)__popcll(k2 & below);
+                if (keep1) {
+                    stack_store(&qa[w], make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x));
+                    stack_store(&qb[w], make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y));
+                    stack_store(&qc[w], make_float4(b.f1.z, __uint_as_float(spix), __uint_as_float(snode * 2u), __uint_as_float(ss0)));
+                }
+                if (push2) {
+                    const uint32_t w2 = w + (keep1 ? 1u : 0u);
+                    stack_store(&qa[w2], make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x));
+                    stack_store(&qb[w2], make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y));
+                    stack_store(&qc[w2], make_float4(b.f2.z, __uint_as_float(spix), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0)));
+                }
+                if (takeOwn) {
+                    o = b.o2; d = b.d2; beta = b.f2; pix = spix; node = snode * 2u + 1u; s0 = ss0;
+                    r = ray_pre<kShortRcp>(o, d);
+                    h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
+                    tsp = 0;
+                    if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, kTerm); else MIPT_STACK_PUSH(lstk, deep, tsp, kTerm);
+                    cur = 0; active = true; traced++;
+                    if ((32u - (uint32_t)__clz((int)node)) >= A.F.maxDepth) {     // last level: the emitters' tree first
+                        if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, 0u); else MIPT_STACK_PUSH(lstk, deep, tsp, 0u);
+                        cur = A.S.emitRoot;
+                    }
+                    if (A.pixelRays) atomicAdd(A.pixelRays + pix, 1u);
+                }
+                sp += (uint32_t)__popcll(k1) + (uint32_t)__popcll(k2);          // (<= 2 n: within the room the batch was sized for)
+                continue;
+            }
             const bool takeOwn = !NEE && has && !active;
             const unsigned long long tk = NEE ? 0ull : MIPT_BALLOT(takeOwn);
             const uint32_t total = 2u * n + nEnvRays + (uint32_t)__popcll(em) - (uint32_t)__popcll(tk);
@@ -949,6 +1027,10 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                     tsp = 0;
                     if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, kTerm); else MIPT_STACK_PUSH(lstk, deep, tsp, kTerm);
                     cur = 0;
+                    if constexpr (emitFirst) if ((32u - (uint32_t)__clz((int)node)) >= A.F.maxDepth) {         // last level: the emitters' tree first
+                        if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, 0u); else MIPT_STACK_PUSH(lstk, deep, tsp, 0u);
+                        cur = A.S.emitRoot;
+                    }
                     active = true;
                     traced++;
                     if constexpr (NEE) if (pix & kShadowBit) { shadowTraced++; h.t = __uint_as_float(node); }    // stops short of the emitter
@@ -1148,7 +1230,17 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                 if constexpr (NEE) if ((pix & kShadowBit) && h.tri >= 0) cur = kTerm;      // occlusion ray: any hit ends it
                 // no emitting mesh in the scene: a last-level ray adds nothing if it hits anything, so its first hit ends it
                 // (its level is recomputed from the node id: cheaper than a register held through the traversal)
-                if (A.S.emissiveMeshes == 0u) { if (h.tri >= 0 && (32u - (uint32_t)__clz((int)node)) >= A.F.maxDepth) cur = kTerm; }
+                if constexpr (!emitFirst) { if (A.S.emissiveMeshes == 0u) { if (h.tri >= 0 && (32u - (uint32_t)__clz((int)node)) >= A.F.maxDepth) cur = kTerm; } }
+                else {
+                    // emitters first (see above): a last-level ray ends at the first hit on something that does not emit; under a
+                    // black sky it also ends when the emitters' tree is exhausted without a hit (the entry just popped is the main
+                    // root, reference 0, which sits on no other ray's stack) or, having slipped into the main tree, at its next leaf
+                    if ((32u - (uint32_t)__clz((int)node)) >= A.F.maxDepth) {
+                        const bool emits = (__float_as_uint(h.u) >> 31) != 0u;
+                        const bool over = h.tri >= 0 ? !emits : (skyBlack && (cur == 0u || (cnt != 0u && first < A.S.nRefsMain)));      // (cnt 0: an empty slot's reference, not a leaf of the main tree)
+                        if (over) cur = kTerm;
+                    }
+                }
             }
         }
         again = false;
@@ -1226,7 +1318,12 @@ void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
         else hipLaunchKernelGGL((k_wavestack<false, false, true, true>), dim3(blocks * 4), dim3(64), 0, s, a);
     }
     else if (a.nee == 2u) {      // estimator 2: VNDF specular + cosine diffuse, no occlusion rays
-        if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false, true>), dim3(blocks * 4), dim3(64), 0, s, a);
+        if (a.S.emitRoot) {
+            if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false, true, true>), dim3(blocks * 4), dim3(64), 0, s, a);
+            else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, false, true, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+            else hipLaunchKernelGGL((k_wavestack<false, false, false, true, true>), dim3(blocks * 4), dim3(64), 0, s, a);
+        }
+        else if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false, true>), dim3(blocks * 4), dim3(64), 0, s, a);
         else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
         else hipLaunchKernelGGL((k_wavestack<false, false, false, true>), dim3(blocks * 4), dim3(64), 0, s, a);
     }
@@ -1234,6 +1331,11 @@ void launch_wavestack(const StackArgs& a, int blocks, hipStream_t s) {
         if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, true>), dim3(blocks * 4), dim3(64), 0, s, a);
         else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
         else hipLaunchKernelGGL((k_wavestack<false, false, true>), dim3(blocks * 4), dim3(64), 0, s, a);
+    }
+    else if (a.S.emitRoot) {     // the reference's estimator in a scene with an emitters' tree
+        if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false, false, true>), dim3(blocks * 4), dim3(64), 0, s, a);
+        else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, false, false, true>), dim3(blocks), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_wavestack<false, false, false, false, true>), dim3(blocks * 4), dim3(64), 0, s, a);
     }
     else if (a.S.wide) hipLaunchKernelGGL((k_wavestack<false, true, false>), dim3(blocks * 4), dim3(64), 0, s, a);
     else if (lds) hipLaunchKernelGGL((k_wavestack<true, false, false>), dim3(blocks), dim3(kBlock), 0, s, a);

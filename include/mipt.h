@@ -180,7 +180,18 @@ int  mipt_scene_bvh_was_cached(const mipt_scene*);
  * 0 without an env map.  No counterpart in the reference (it has no light sampling). */
 uint64_t mipt_scene_get_env_cdf(const mipt_scene*, float* out, uint64_t cap);
 /* emitter table of estimator 1: n x 15 floats [v0 e1 e2 unit-normal Le] and the area CDF [n+1]; returns n */
-uint64_t mipt_scene_get_emitters(const mipt_scene*, float* tris, float* cdf, uint64_t cap_tris);          /* 1 if the BVH came from desc.bvhCachePath, 0 if it was built */
+uint64_t mipt_scene_get_emitters(const mipt_scene*, float* tris, float* cdf, uint64_t cap_tris);
+/* "Emitters first" (no counterpart in the reference, which traces every ray to its closest hit, CUDATracerProg.cu:543-794).  A ray
+ * at the last level can only add emission (or the sky): in a scene where some meshes emit and some do not, the wave-stack
+ * integrator (estimators 0 and 2) intersects such a ray with a small second tree over the emitting triangles first, then walks the
+ * main tree with that distance as its bound and stops at the first hit on anything that does not emit; under a black sky a ray that
+ * found no emitter is finished at once.  Same image and the same per-pixel ray counts (the ray is still intersected with everything
+ * that can change its contribution).  The second tree lies behind the main tree in the device arrays, in the same node layout; this
+ * returns it as it lies there (node indices and leaf ranges continue the main tree's: concatenate with mipt_scene_get_bvh's arrays)
+ * with its root reference -- an inner node index, or a leaf reference when the emitters fit one leaf; *root_ref = 0: the scene has
+ * none (nothing or everything emits, or the tree would not fit the traversal stack / the LDS window the main tree fits).
+ * $MIPT_EMITTER_TREE=0 builds none. */
+int mipt_scene_get_emitter_tree(const mipt_scene*, float* nodes, uint32_t* n_nodes, float* refs, uint32_t* n_refs, uint32_t* root_ref);
 
 /* ---- the hot path: PathTracer::Trace (CUDATracer.hpp:352-358; CUDATracerProg.cu:937-963) -------------------
  * One sample per pixel for sample index settings->frameID, folded into acc_dev (w*h*4 floats, running mean with

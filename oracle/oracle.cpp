@@ -415,6 +415,7 @@ struct orc_scene {
     uint32_t fwidth = 2;             // 2: BVH2 nodes, 4: quantised 4-wide nodes
     int estimator = 0;
     bool anyhitLast = false, anyEmits = false;     // see LaunchRayRecur
+    uint32_t emitRoot = 0, nRefsMain = 0;          // the product's "emitters first" rule (orc_scene_set_emitter_tree); 0 = off
     std::vector<float> envCdf;       // rowCdf[H+1], then H x colCdf[W+1]
     float neeScale = 0.f;            // pi / (0.98 * W * H): p_cap * texel solid angle / sin(theta)
     // emissive triangles (estimator 1): 15 floats each [v0 e1 e2 n Le], area CDF [n+1], total area / (2 pi 0.98)
@@ -424,7 +425,7 @@ struct orc_scene {
 namespace {
 
 struct Hit { float t, u, v; int tri; bool front; };   // tri = global id
-struct alignas(128) Counters { uint64_t rays = 0, nodes = 0, tris = 0, hits = 0, shadow = 0, anyhit = 0; };   // one cache line per thread
+struct alignas(128) Counters { uint64_t rays = 0, nodes = 0, tris = 0, hits = 0, shadow = 0, anyhit = 0, emitfirst = 0; };   // one cache line per thread
 
 // Moller-Trumbore on (v0, e1, e2) -- CUDATracerProg.cu:232-263.  Accepts iff t>0 && t<tmin (strict), or -- when
 // `id`/`bestId` are given (>= 0) -- on an exact tie t==tmin if the candidate's global triangle id is lower.  The
@@ -521,12 +522,22 @@ Hit isect_brute(const orc_scene& s, v3 o, v3 d, Counters* c) {
 //     inner = node index.  Order: nearer child first, farther pushed; leaves tested when they become current; hitT
 //     shrinks as hits are found and culls later box tests (tnear <= hitT).  No re-test at pop. ---
 inline int32_t fbits(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
-Hit isect_flat(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false) {
+// How a ray ends early in the product's wave-stack integrator (kernels.hip, phase D; work-counting options, same image):
+//   kClosest     -- never: the closest hit
+//   kAnyhit      -- at the end of the first leaf that left it with a hit (last-level ray, no mesh of the scene emits)
+//   kEmitFirst   -- last-level ray in a scene with emitters: it starts in the emitters' tree with the main root waiting on the
+//                   stack; at the end of a leaf it is over if its closest hit so far does not emit, or -- under a black sky, no
+//                   hit yet -- if the entry it is about to pop is the main root or the leaf belonged to the main tree
+enum FlatEnd { kClosest = 0, kAnyhit = 1, kEmitFirst = 2 };
+inline bool sky_black(const orc_scene& s) { return s.env.empty() && s.sky.intensity == 0.f; }
+Hit isect_flat(const orc_scene& s, v3 o, v3 d, Counters* c, int end = kClosest) {
     RayPre r = ray_pre(o, d);
     Hit best; best.t = INFINITY; best.tri = -1; best.u = best.v = 0; best.front = false;
     if (s.fnodes.empty()) return best;
     uint32_t stack[128]; int sp = 0;
     uint32_t cur = 0;
+    bool bestEmits = false; const bool black = sky_black(s);
+    if (end == kEmitFirst) { stack[sp++] = 0u; cur = s.emitRoot; }
     while (true) {
         if (cur & 0x80000000u) {
             uint32_t cnt = (cur >> 27) & 0xF, first = cur & 0x07FFFFFFu;
@@ -534,10 +545,11 @@ Hit isect_flat(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false)
                 const float* T = &s.ftris[(size_t)i * 12]; c->tris++;
                 float tt, uu, vv; bool ff;
                 if (mt_test(o, d, ld3(T), ld3(T + 4), ld3(T + 8), best.t, &tt, &uu, &vv, &ff, fbits(T[3]), best.tri)) {
-                    best.t = tt; best.u = uu; best.v = vv; best.front = ff; best.tri = fbits(T[3]);
+                    best.t = tt; best.u = uu; best.v = vv; best.front = ff; best.tri = fbits(T[3]); bestEmits = (fbits(T[11]) & 2) != 0;
                 }
             }
-            if (anyhit && best.tri >= 0) return best;          // the product's last-level shortcut: the leaf is finished, then the ray ends
+            if (end == kAnyhit && best.tri >= 0) return best;  // the product's last-level shortcut: the leaf is finished, then the ray ends
+            if (end == kEmitFirst && (best.tri >= 0 ? !bestEmits : (black && ((sp > 0 && stack[sp - 1] == 0u) || (cnt != 0u && first < s.nRefsMain))))) return best;
         } else {
             const float* N = &s.fnodes[(size_t)cur * 16]; c->nodes++;
             float t0, t1;
@@ -565,12 +577,14 @@ Hit isect_flat(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false)
 //     quantised frame exactly as the kernel does (kernels.hip wide_visit): t = q * (idir * scale) + (origin - o) * idir.  Hit children are visited nearest
 //     first (5-exchange sorting network, swap iff tb < ta), the others pushed farthest first. ---
 inline float ubits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false) {
+Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c, int end = kClosest) {
     RayPre r = ray_pre(o, d);
     Hit best; best.t = INFINITY; best.tri = -1; best.u = best.v = 0; best.front = false;
     if (s.fnodes.empty()) return best;
     uint32_t stack[256]; int sp = 0;
     uint32_t cur = 0;
+    bool bestEmits = false; const bool black = sky_black(s);
+    if (end == kEmitFirst) { stack[sp++] = 0u; cur = s.emitRoot; }
     while (true) {
         if (cur & 0x80000000u) {
             uint32_t cnt = (cur >> 27) & 0xF, first = cur & 0x07FFFFFFu;
@@ -578,10 +592,11 @@ Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false
                 const float* T = &s.ftris[(size_t)i * 12]; c->tris++;
                 float tt, uu, vv; bool ff;
                 if (mt_test(o, d, ld3(T), ld3(T + 4), ld3(T + 8), best.t, &tt, &uu, &vv, &ff, fbits(T[3]), best.tri)) {
-                    best.t = tt; best.u = uu; best.v = vv; best.front = ff; best.tri = fbits(T[3]);
+                    best.t = tt; best.u = uu; best.v = vv; best.front = ff; best.tri = fbits(T[3]); bestEmits = (fbits(T[11]) & 2) != 0;
                 }
             }
-            if (anyhit && best.tri >= 0) return best;          // the product's last-level shortcut: the leaf is finished, then the ray ends
+            if (end == kAnyhit && best.tri >= 0) return best;  // the product's last-level shortcut: the leaf is finished, then the ray ends
+            if (end == kEmitFirst && (best.tri >= 0 ? !bestEmits : (black && ((sp > 0 && stack[sp - 1] == 0u) || (cnt != 0u && first < s.nRefsMain))))) return best;
         } else {
             const float* N = &s.fnodes[(size_t)cur * 16]; c->nodes++;
             const float ix = r.idir.x * N[10], iy = r.idir.y * N[11], iz = r.idir.z * N[3];
@@ -597,7 +612,10 @@ Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false
                 float tlz = ffma((float)((lz >> sh) & 0xFFu), iz, oz), thz = ffma((float)((hz >> sh) & 0xFFu), iz, oz);
                 float tmin = fmax_(fmax_(fmin_(tlx, thx), fmin_(tly, thy)), fmax_(fmin_(tlz, thz), 0.0f));
                 float tmax = fmin_(fmin_(fmax_(tlx, thx), fmax_(tly, thy)), fmin_(fmax_(tlz, thz), best.t));
-                const bool hit = tmin <= tmax;      // empty slots carry an inverted box (and a zero-triangle leaf reference)
+                // empty slots carry an inverted box and a zero-triangle leaf reference.  The kernel picks entry / exit planes by the
+                // ray's octant, which an inverted box never passes; min / max per axis, as written here, would turn it the right
+                // way round again, so the reference is looked at as well (same decision as the kernel's for every slot)
+                const bool hit = tmin <= tmax && ref[i] != 0x80000000u;
                 t[i] = hit ? tmin : INFINITY;
                 n += hit ? 1 : 0;
             }
@@ -616,9 +634,9 @@ Hit isect_flat4(const orc_scene& s, v3 o, v3 d, Counters* c, bool anyhit = false
     }
     return best;
 }
-inline Hit isect(const orc_scene& s, int mode, v3 o, v3 d, Counters* c, bool anyhit = false) {
+inline Hit isect(const orc_scene& s, int mode, v3 o, v3 d, Counters* c, int end = kClosest) {
     c->rays++;
-    Hit h = mode == ORC_ISECT_REF ? isect_ref(s, o, d, c) : mode == ORC_ISECT_FLAT ? (s.fwidth == 4 ? isect_flat4(s, o, d, c, anyhit) : isect_flat(s, o, d, c, anyhit)) : isect_brute(s, o, d, c);
+    Hit h = mode == ORC_ISECT_REF ? isect_ref(s, o, d, c) : mode == ORC_ISECT_FLAT ? (s.fwidth == 4 ? isect_flat4(s, o, d, c, end) : isect_flat(s, o, d, c, end)) : isect_brute(s, o, d, c);
     if (h.tri >= 0) c->hits++;
     return h;
 }
@@ -836,8 +854,14 @@ v3 LaunchRayRecur(Ctx& k, v3 o, v3 d, int ttl, Lcg* dfs, uint32_t node, bool noE
     // last-level ray at its first hit when no mesh of the scene emits -- such a ray adds nothing if it hits anything.  The
     // image is the same either way; only node visits / triangle tests (the roofline's algorithmic counts) change.
     const bool anyhit = k.s->anyhitLast && ttl == 1 && !k.s->anyEmits;
+    // ... and in a scene with emitters and an emitters' tree (orc_scene_set_emitter_tree; estimators 0 and 2, as in the product)
+    // the last-level ray takes the "emitters first" route: what it returns below -- the emission of its hit, or the sky -- is
+    // what the closest hit would have given (an emitter that is the closest hit is found and not occluded; any other hit has no
+    // emission to add; a miss is a miss either way)
+    const bool emitFirst = k.s->anyhitLast && ttl == 1 && k.s->anyEmits && k.s->emitRoot != 0u && k.isect == ORC_ISECT_FLAT && (k.s->estimator == 0 || k.s->estimator == 2);
     if (anyhit) k.c->anyhit++;
-    Hit h = isect(*k.s, k.isect, o, d, k.c, anyhit);
+    if (emitFirst) k.c->emitfirst++;
+    Hit h = isect(*k.s, k.isect, o, d, k.c, anyhit ? kAnyhit : emitFirst ? kEmitFirst : kClosest);
     if (h.tri < 0) return noEnv ? color : OnMiss(k, d);
     if (anyhit) return color;
     const OMesh& m = k.s->meshes[k.s->triMesh[h.tri]];
@@ -1035,6 +1059,17 @@ int orc_scene_set_flat_bvh(orc_scene* s, const float* nodes, uint32_t n_nodes, c
     s->fnodes.assign(nodes, nodes + (size_t)n_nodes * 16);
     s->ftris.assign(tris, tris + (size_t)n_refs * 12);
     s->fwidth = 2;
+    s->emitRoot = 0; s->nRefsMain = 0;      // (a new tree: orc_scene_set_emitter_tree is called after this, if at all)
+    return 0;
+}
+int orc_scene_set_emitter_tree(orc_scene* s, uint32_t root_ref, uint32_t n_refs_main) {
+    const size_t nNodes = s->fnodes.size() / 16, nRefs = s->ftris.size() / 12;
+    if (root_ref != 0u) {        // the tree lies behind the main tree in the arrays orc_scene_set_flat_bvh* was given
+        if (n_refs_main > nRefs) return 1;
+        if (root_ref & 0x80000000u) { const uint32_t cnt = (root_ref >> 27) & 0xFu, first = root_ref & 0x07FFFFFFu; if (first < n_refs_main || (size_t)first + cnt > nRefs) return 1; }
+        else if (root_ref >= nNodes) return 1;
+    }
+    s->emitRoot = root_ref; s->nRefsMain = n_refs_main;
     return 0;
 }
 int orc_scene_set_estimator(orc_scene* s, int e) { if (e < 0 || e > 3) return 1; s->estimator = e; return 0; }
@@ -1121,7 +1156,7 @@ int orc_trace_rays(const orc_scene* s, int mode, const float* origins, const flo
             o.t = h.t; o.u = h.u; o.v = h.v; o.tri = h.tri; o.mesh = h.tri >= 0 ? (int32_t)s->triMesh[h.tri] : -1; o.front = h.front ? 1 : 0;
         }
     });
-    if (stats) { memset(stats, 0, sizeof *stats); for (auto& c : cs) { stats->rays += c.rays; stats->node_visits += c.nodes; stats->tri_tests += c.tris; stats->hits += c.hits; stats->shadow_rays += c.shadow; stats->anyhit_rays += c.anyhit; } }
+    if (stats) { memset(stats, 0, sizeof *stats); for (auto& c : cs) { stats->rays += c.rays; stats->node_visits += c.nodes; stats->tri_tests += c.tris; stats->hits += c.hits; stats->shadow_rays += c.shadow; stats->anyhit_rays += c.anyhit; stats->emitfirst_rays += c.emitfirst; } }
     return 0;
 }
 
@@ -1159,7 +1194,7 @@ int orc_render(const orc_scene* s, const orc_settings* st, int isect_mode, int r
             }
         });
     }
-    if (stats) { memset(stats, 0, sizeof *stats); for (auto& c : cs) { stats->rays += c.rays; stats->node_visits += c.nodes; stats->tri_tests += c.tris; stats->hits += c.hits; stats->shadow_rays += c.shadow; stats->anyhit_rays += c.anyhit; } }
+    if (stats) { memset(stats, 0, sizeof *stats); for (auto& c : cs) { stats->rays += c.rays; stats->node_visits += c.nodes; stats->tri_tests += c.tris; stats->hits += c.hits; stats->shadow_rays += c.shadow; stats->anyhit_rays += c.anyhit; stats->emitfirst_rays += c.emitfirst; } }
     return 0;
 }
 

@@ -74,6 +74,7 @@ typedef struct {
     uint64_t hits;        /* rays that hit something */
     uint64_t shadow_rays; /* of `rays`: occlusion rays of the env-map importance sampling estimator (estimator 1) */
     uint64_t anyhit_rays; /* of `rays`: last-level rays traced under orc_scene_set_anyhit_last_level's hit-or-miss rule */
+    uint64_t emitfirst_rays; /* of `rays`: last-level rays traced under the "emitters first" rule (orc_scene_set_emitter_tree) */
 } orc_stats;
 
 typedef struct { float t, u, v; int32_t tri; int32_t mesh; int32_t front; } orc_hit; /* tri = global triangle id, -1 = miss */
@@ -129,6 +130,11 @@ int orc_scene_set_estimator(orc_scene*, int estimator);
 /* work-counting option for the FLAT intersector: last-level rays stop at their first hit when no mesh emits (what the product
  * does; same image, fewer node visits / triangle tests).  Off by default: every other mode is the reference's closest hit. */
 int orc_scene_set_anyhit_last_level(orc_scene*, int on);
+/* Work-counting option, with orc_scene_set_anyhit_last_level on (FLAT intersector, estimators 0 and 2): restates the product's
+ * "emitters first" rule for last-level rays in a scene with emitters (include/mipt.h mipt_scene_get_emitter_tree; kernels.hip phase D).
+ * The flat arrays given to orc_scene_set_flat_bvh* must hold the emitters' tree behind the main tree; root_ref = its root reference
+ * (0 = off), n_refs_main = the main tree's reference count.  Same image bit for bit; fewer node visits / triangle tests. */
+int orc_scene_set_emitter_tree(orc_scene*, uint32_t root_ref, uint32_t n_refs_main);
 /* the sampling tables of estimator 1: rowCdf[H+1] then H rows of colCdf[W+1]; returns the float count (0 = no env map) */
 uint64_t orc_scene_get_env_cdf(const orc_scene*, float* out, uint64_t cap);
 

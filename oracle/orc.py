@@ -49,7 +49,7 @@ class SceneDesc(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("hits", C.c_uint64),
-                ("shadow_rays", C.c_uint64), ("anyhit_rays", C.c_uint64)]
+                ("shadow_rays", C.c_uint64), ("anyhit_rays", C.c_uint64), ("emitfirst_rays", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("tri", "<i4"), ("mesh", "<i4"), ("front", "<i4")])
@@ -85,6 +85,7 @@ lib.orc_check_flat_bvh.argtypes = [_vp, C.c_char_p, C.c_uint32]
 lib.orc_scene_set_flat_width.argtypes = [_vp, C.c_uint32]
 lib.orc_scene_set_estimator.argtypes = [_vp, C.c_int]
 lib.orc_scene_set_anyhit_last_level.argtypes = [_vp, C.c_int]
+lib.orc_scene_set_emitter_tree.argtypes = [_vp, C.c_uint32, C.c_uint32]
 lib.orc_scene_get_env_cdf.argtypes = [_vp, _vp, C.c_uint64]
 lib.orc_scene_get_env_cdf.restype = C.c_uint64
 lib.orc_scene_get_emitters.argtypes = [_vp, _vp, _vp, C.c_uint64]
@@ -179,6 +180,12 @@ class Scene:
     def set_anyhit_last_level(self, on=True):
         """FLAT intersector: last-level rays end at their first hit when no mesh emits (the product's shortcut); counts only."""
         lib.orc_scene_set_anyhit_last_level(self.h, 1 if on else 0)
+
+    def set_emitter_tree(self, root_ref, n_refs_main):
+        """counting option: the product's "emitters first" rule for last-level rays (needs set_anyhit_last_level and flat
+        arrays that hold the emitters' tree behind the main tree); root_ref 0 switches it off"""
+        if lib.orc_scene_set_emitter_tree(self.h, int(root_ref), int(n_refs_main)) != 0:
+            raise ValueError("emitters' tree does not lie inside the flat arrays")
 
     def set_estimator(self, estimator):
         """0 = the reference's estimator, 1 = light sampling, 2 = VNDF + cosine lobes, 3 = both (specification: include/mipt.h)."""
