@@ -305,11 +305,35 @@ def run_workload(name, a, ctx, cpu_seconds):
     for k in range(1, n_rep):
         reps.append(timed_repeat(a.warmup + k * a.steps))
     t.set_option("profile_levels", 0)
+    cnt = t.counters()                 # (read before anything else is rendered)
+    prof = t.level_profile()
+    # Beside the headline, for a scene with an emitters' tree: the same frames with every ray traced to its closest hit (the scene
+    # built without the second tree), so that the line shows what the "emitters first" rule is worth and what the rate is without it
+    closest_only = None
+    if not multi and a.integrator == 0 and a.estimator in (0, 2) and sc.emitter_tree()[2] and not os.environ.get("MIPT_EMITTER_TREE"):
+        os.environ["MIPT_EMITTER_TREE"] = "0"
+        try:
+            plain = pt.Scene(t, data, node_width=a.node_width, tri_cost=a.tri_cost, max_leaf=a.max_leaf)
+        finally:
+            del os.environ["MIPT_EMITTER_TREE"]
+        for i in range(a.warmup):
+            t.render(plain, settings, i, 1, acc.data_ptr(), ldr.data_ptr(), 1, 0)
+        t.synchronize()
+        times, r0 = [], t.counters().rays
+        while sum(times) < min(a.min_seconds, 1.0) or not times:
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                t.render(plain, settings, a.warmup + len(times) * a.steps + i, 1, acc.data_ptr(), ldr.data_ptr(), 1, 0)
+            t.synchronize()
+            times.append(time.perf_counter() - t0)
+        rays_plain = (t.counters().rays - r0) / (len(times) * a.steps)
+        med = sorted(times)[len(times) // 2]
+        closest_only = {"value": round(rays_plain * a.steps / med / 1e6, 1), "unit": "Mrays/s", "ms_per_step": round(med / a.steps * 1e3, 3),
+                        "note": "same frames, scene built without the emitters' tree ($MIPT_EMITTER_TREE=0): every ray traced to its closest hit"}
+        plain.close()
     order = sorted(range(len(reps)), key=lambda k: reps[k][0])
     dt, total_rays, total_shadow = reps[order[len(order) // 2]]            # the median repeat
     timed_s = sum(r[0] for r in reps)
-    cnt = t.counters()
-    prof = t.level_profile()
     out = None
     if rank == 0:
         nodes, refs = sc.bvh()
@@ -416,6 +440,7 @@ def run_workload(name, a, ctx, cpu_seconds):
             # first, then walked through the scene only as far as it takes to know whether that emitter is the closest hit (same
             # image; a ray that can add nothing costs two triangle tests on the Cornell box)
             "emitter_first_ray_frac": None if cpu is None else round(cpu["emitfirst"], 4),
+            "closest_hit_only": closest_only,
             "accumulate_ms": round(prof.accumulate_ms / max(launches_total, 1), 3),
             "roofline": roof,
         }

@@ -52,7 +52,15 @@ def test_bench_prints_one_json_line_with_the_contract_keys(extra):
         assert d["kernel_span_ms_per_step"] > 0
         tl = d["trace_loop"]          # the reference's call sequence: Trace + blocking bitmap read-back per frame
         assert tl["ms_per_frame"] > 0 and tl["mrays_per_s"] > 0 and tl["frames"] == 6 and tl["ldr_bytes_per_frame"] == 320 * 180 * 4
-        assert (d["anyhit_ray_frac"] > 0.2) == (extra[1] == "default")     # Default has no emitting mesh: its last-level rays are hit-or-miss; Cornell's lamp keeps them closest-hit
+        assert (d["anyhit_ray_frac"] > 0.2) == (extra[1] == "default")     # Default has no emitting mesh: its last-level rays are hit-or-miss
+        # Cornell has a lamp: its last-level rays go through the emitters' tree first, and the line says so and carries the rate of
+        # the same frames with every ray traced to its closest hit
+        if extra[1] == "cornell":
+            assert d["emitter_first_ray_frac"] > 0.2 and d["roofline"]["kernel"].endswith(", true>")
+            ch = d["closest_hit_only"]
+            assert ch["value"] > 0 and ch["ms_per_step"] > 0 and "closest hit" in ch["note"]
+        else:
+            assert d["emitter_first_ray_frac"] == 0 and d["closest_hit_only"] is None
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "Mrays/s" and cb["value"] > 0 and 1 <= cb["cores"] <= 16 and cb["sample"]
     if "--estimator" in extra:
