@@ -83,6 +83,7 @@ def parse():
     p.add_argument("--pipeline", type=int, default=1, help="1 (default): consecutive frames alternate between two streams so a frame's tail overlaps the next frame; 0: one stream")
     p.add_argument("--estimator", type=int, default=0, help="0 the reference's estimator (default, the parity configuration); 1 env-map / emitter sampling with occlusion rays; 2 VNDF-sampled specular + cosine-weighted diffuse lobes; 3 both")
     p.add_argument("--option", action="append", default=[], help="key=value passed to mipt_set_option (tuning experiments)")
+    p.add_argument("--closest-hit-only", type=int, default=1, help="1 (default): a scene with an emitters' tree is also timed without it, reported as closest_hit_only; 0: skip (counter passes: one kernel variant per run)")
     return p.parse_args()
 
 
@@ -310,7 +311,7 @@ def run_workload(name, a, ctx, cpu_seconds):
     # Beside the headline, for a scene with an emitters' tree: the same frames with every ray traced to its closest hit (the scene
     # built without the second tree), so that the line shows what the "emitters first" rule is worth and what the rate is without it
     closest_only = None
-    if not multi and a.integrator == 0 and a.estimator in (0, 2) and sc.emitter_tree()[2] and not os.environ.get("MIPT_EMITTER_TREE"):
+    if a.closest_hit_only and not multi and a.integrator == 0 and a.estimator in (0, 2) and sc.emitter_tree()[2] and not os.environ.get("MIPT_EMITTER_TREE"):
         os.environ["MIPT_EMITTER_TREE"] = "0"
         try:
             plain = pt.Scene(t, data, node_width=a.node_width, tri_cost=a.tri_cost, max_leaf=a.max_leaf)

@@ -13,7 +13,7 @@ cd /tmp
 export PYTHONPATH=$R
 for w in "${WL[@]}"; do
   echo "== $w: kernel trace of the bench measurement"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw_$w -o kt -- python3 $R/bench.py --workload $w --cpu-seconds 0 --trace-loop-frames 0 --min-seconds 2 > $OUT/bench_under_rocprof_$w.json 2> $OUT/bench_under_rocprof_$w.err || { echo "kernel trace failed for $w"; tail -3 $OUT/bench_under_rocprof_$w.err; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw_$w -o kt -- python3 $R/bench.py --workload $w --cpu-seconds 0 --trace-loop-frames 0 --closest-hit-only 0 --min-seconds 2 > $OUT/bench_under_rocprof_$w.json 2> $OUT/bench_under_rocprof_$w.err || { echo "kernel trace failed for $w"; tail -3 $OUT/bench_under_rocprof_$w.err; exit 1; }
   cp $(find $OUT/raw_$w -name '*kernel_stats.csv' | head -1) $OUT/${w}_default_cmd_kernel_stats.csv
   python3 $R/scripts/kt_steady.py $(find $OUT/raw_$w -name '*kernel_trace.csv' | head -1) 4 k_wavestack 32 > $OUT/${w}_default_cmd_steady.csv || exit 1
   cat $OUT/${w}_default_cmd_steady.csv
@@ -22,7 +22,7 @@ import json; d=json.loads(open('$OUT/bench_under_rocprof_$w.json').read().strip(
 print(' bench under rocprofv3:', d['value'], 'Mrays/s,', d['ms_per_step'], 'ms/step, kernel_window_ms (mean event window)', d['kernel_window_ms'], 'kernel_span_ms_per_step', d['kernel_span_ms_per_step'])"
   rm -rf $OUT/raw_$w
   echo "== $w: pmc"
-  bash $R/scripts/pmc_passes.sh r3_$w --workload $w --trace-loop-frames 0 || { echo "pmc failed for $w"; exit 1; }
+  bash $R/scripts/pmc_passes.sh r3_$w --workload $w --trace-loop-frames 0 --closest-hit-only 0 || { echo "pmc failed for $w"; exit 1; }
   python3 $R/scripts/pmc_summary.py $R/gpurun_out/pmc_r3_$w > $OUT/pmc_${w}.txt
 done
 args=(); for w in "${WL[@]}"; do args+=("$w=$R/gpurun_out/pmc_r3_$w"); done
