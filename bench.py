@@ -426,7 +426,12 @@ def run_workload(name, a, ctx, cpu_seconds):
             "config": {"workload": f"{name}_{W}x{H}_{depth}bounce_1spp_per_gpu_step" + (f"_n{a.grid_n}" if name == "grid" else ""), "baseline_config": WORKLOADS[name][0],
                        "width": W, "height": H, "max_depth": depth,
                        "triangles": data.triangle_count, "bvh": "sbvh" + ("-q4" if sc.bvh_width == 4 else ""), "rng": "node", "integrator": "wave-stacks" if a.integrator == 0 else "level-queues", "parallelism": f"sample-striding x{world}",
-                       "env_map": None if data.env is None else "synthetic 2048x1024"},
+                       "env_map": None if data.env is None else "synthetic 2048x1024",
+                       # how last-level rays (which can only add emission or the sky) are traced; the image and the per-pixel ray
+                       # counts are those of closest-hit tracing in every case
+                       "last_level_rays": ("emitters first, then the scene up to the first non-emitter (closest_hit_only gives the rate without it)" if sc.emitter_tree()[2] and a.estimator in (0, 2) and a.integrator == 0
+                                           else "first hit ends them (no mesh emits)" if a.integrator == 0 and a.estimator in (0, 2) and not any(m[2].emissiveStrength != 0 and any(c != 0 for c in m[2].emissiveColor) for m in data.meshes)
+                                           else "closest hit")},
             "spp_per_s": round(a.steps * world / dt, 3), "rays_per_step_per_gpu": round(total_rays / a.steps / world, 1),
             "shadow_rays": round(total_shadow / a.steps / world, 1),
             # kernel_window_ms: mean of the launches' own HIP-event windows (= rocprofv3's average kernel duration); pipelined
