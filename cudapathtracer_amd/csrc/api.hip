@@ -13,10 +13,13 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -347,31 +350,61 @@ bool save_bvh_cache(const char* path, uint64_t key, uint32_t nTris, const BvhOut
 }
 
 // flattens the meshes of a desc: triangle positions, mesh id per triangle, and the 12-float shading record per triangle
+// chunks [b, e) of [0, n) on up to 16 host threads ($MIPT_BUILD_THREADS); small ranges run on the caller's thread
+template <class F> void parallel_chunks(size_t n, F f) {
+    int threads = (int)std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("MIPT_BUILD_THREADS")) threads = std::atoi(e);
+    threads = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+    if (n < (1u << 16) || threads == 1) { f((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t step = (n + threads - 1) / threads;
+    try {
+        for (size_t b = step; b < n; b += step) th.emplace_back(f, b, std::min(n, b + step));
+    } catch (...) { for (auto& x : th) x.join(); throw; }
+    f((size_t)0, std::min(n, step));
+    for (auto& x : th) x.join();
+}
+
 int gather_geometry(mipt_tracer* t, const mipt_scene_desc* d, std::vector<TriPos>& tris, std::vector<uint32_t>& triMesh, std::vector<float>& shade) {
     if (d->meshCnt && !d->meshes) return fail(t, MIPT_E_INVALID, "meshes is null");
+    size_t total = 0;
     for (uint32_t m = 0; m < d->meshCnt; m++) {
         const mipt_mesh_desc& md = d->meshes[m];
         if (md.indicesCnt % 3) return fail(t, MIPT_E_INVALID, "indicesCnt is not a multiple of 3");
         if (md.indicesCnt && (!md.indices || !md.vertices)) return fail(t, MIPT_E_INVALID, "mesh arrays are null");
-        for (uint32_t i = 0; i < md.indicesCnt; i += 3) {
-            TriPos tp; float nn[3][3];
-            for (int k = 0; k < 3; k++) {
-                uint32_t vi = md.indices[i + k];
-                if (vi >= md.vertexCnt) return fail(t, MIPT_E_INVALID, "vertex index out of range");
-                memcpy(tp.v[k], md.vertices[vi].position, 12);
-                // finite and below 2^40: the integrator's short reciprocals (kernels.hip mt_test<true>) are bit-exact for
-                // |det| <= 2^100, which unit-scale directions and edges of at most 2^41 keep far away
-                for (int a = 0; a < 3; a++) if (!(std::fabs(tp.v[k][a]) < 1.099511627776e12f)) return fail(t, MIPT_E_INVALID, "vertex coordinate not finite or beyond 2^40");
-                // unit vertex normal, as the reference normalises at hit time (CUDATracerProg.cu:290-293)
-                const float* n = md.vertices[vi].normal;
-                float len = sqrtf(hdot(n, n));
-                for (int a = 0; a < 3; a++) nn[k][a] = (n[a] * 1.f) / len;
+        total += md.indicesCnt / 3;
+    }
+    tris.resize(total); triMesh.resize(total); shade.resize(total * 12);
+    size_t base = 0;
+    for (uint32_t m = 0; m < d->meshCnt; m++) {
+        const mipt_mesh_desc& md = d->meshes[m];
+        const size_t nt = md.indicesCnt / 3;
+        std::atomic<int> bad{0};          // 1: vertex index out of range, 2: coordinate not finite or beyond 2^40
+        parallel_chunks(nt, [&, m, base](size_t b, size_t e) {
+            for (size_t k3 = b; k3 < e; k3++) {
+                TriPos tp; float nn[3][3];
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t vi = md.indices[k3 * 3 + k];
+                    if (vi >= md.vertexCnt) { bad.store(1); return; }
+                    memcpy(tp.v[k], md.vertices[vi].position, 12);
+                    // finite and below 2^40: the integrator's short reciprocals (kernels.hip rcp_newton) are bit-exact for
+                    // |det| <= 2^100, which unit-scale directions and edges of at most 2^41 keep far away
+                    for (int a = 0; a < 3; a++) if (!(std::fabs(tp.v[k][a]) < 1.099511627776e12f)) { bad.store(2); return; }
+                    // unit vertex normal, as the reference normalises at hit time (CUDATracerProg.cu:290-293)
+                    const float* n = md.vertices[vi].normal;
+                    float len = sqrtf(hdot(n, n));
+                    for (int a = 0; a < 3; a++) nn[k][a] = (n[a] * 1.f) / len;
+                }
+                const size_t g = base + k3;
+                tris[g] = tp; triMesh[g] = m;
+                float rec[12] = { nn[0][0], nn[0][1], nn[0][2], 0, nn[1][0], nn[1][1], nn[1][2], 0, nn[2][0], nn[2][1], nn[2][2], 0 };
+                memcpy(&rec[3], &m, 4);
+                memcpy(&shade[g * 12], rec, 48);
             }
-            tris.push_back(tp); triMesh.push_back(m);
-            float rec[12] = { nn[0][0], nn[0][1], nn[0][2], 0, nn[1][0], nn[1][1], nn[1][2], 0, nn[2][0], nn[2][1], nn[2][2], 0 };
-            memcpy(&rec[3], &m, 4);
-            shade.insert(shade.end(), rec, rec + 12);
-        }
+        });
+        if (bad.load() == 1) return fail(t, MIPT_E_INVALID, "vertex index out of range");
+        if (bad.load() == 2) return fail(t, MIPT_E_INVALID, "vertex coordinate not finite or beyond 2^40");
+        base += nt;
     }
     return MIPT_OK;
 }
@@ -391,13 +424,15 @@ uint32_t count_emissive_meshes(const mipt_scene_desc* d) {
 // shading-record / material fetch to know that it adds nothing.
 void fill_refs(const mipt_scene_desc* d, const std::vector<uint32_t>& refTri, const std::vector<TriPos>& tris, const std::vector<uint32_t>& triMesh, std::vector<float>& refs) {
     refs.resize(refTri.size() * 12);
-    for (size_t r = 0; r < refTri.size(); r++) {
-        uint32_t g = refTri[r]; const TriPos& tp = tris[g];
-        float* R = &refs[r * 12];
-        for (int a = 0; a < 3; a++) { R[a] = tp.v[0][a]; R[4 + a] = tp.v[1][a] - tp.v[0][a]; R[8 + a] = tp.v[2][a] - tp.v[0][a]; }
-        const uint32_t flags = mesh_emits(d->meshes[triMesh[g]].material) ? 2u : 0u;
-        memcpy(&R[3], &g, 4); memcpy(&R[7], &triMesh[g], 4); memcpy(&R[11], &flags, 4);
-    }
+    parallel_chunks(refTri.size(), [&](size_t b, size_t e) {
+        for (size_t r = b; r < e; r++) {
+            uint32_t g = refTri[r]; const TriPos& tp = tris[g];
+            float* R = &refs[r * 12];
+            for (int a = 0; a < 3; a++) { R[a] = tp.v[0][a]; R[4 + a] = tp.v[1][a] - tp.v[0][a]; R[8 + a] = tp.v[2][a] - tp.v[0][a]; }
+            const uint32_t flags = mesh_emits(d->meshes[triMesh[g]].material) ? 2u : 0u;
+            memcpy(&R[3], &g, 4); memcpy(&R[7], &triMesh[g], 4); memcpy(&R[11], &flags, 4);
+        }
+    });
 }
 // ---- the emitters' tree ("emitters first", kernels.h SceneDev::emitRoot) ---------------------------------------------------------
 // Built over the triangles of emitting meshes: up to 15 of them are one leaf (no node at all), more get a tree of their own from
@@ -713,7 +748,11 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
         std::vector<TriPos> tris;
         std::vector<uint32_t> triMesh;
         std::vector<float> shade;     // 12 per triangle
+        const bool verbose = std::getenv("MIPT_BUILD_VERBOSE") != nullptr;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tStart = now();
         if (int rc = gather_geometry(t, d, tris, triMesh, shade)) return rc;
+        const double tGather = now();
         BvhParams bp;
         bp.builder = d->bvhBuilder;
         if (bp.builder != MIPT_BVH_SBVH && bp.builder != MIPT_BVH_MEDIAN && bp.builder != MIPT_BVH_LBVH_GPU) return fail(t, MIPT_E_INVALID, "unknown bvhBuilder");
@@ -747,6 +786,7 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
                 return fail(t, MIPT_E_INVALID, std::string("cannot write BVH cache ") + d->bvhCachePath);
         }
 
+        const double tBuild = now();
         mipt_scene* s = new mipt_scene();
         s->t = t; s->nMeshes = d->meshCnt; s->nTris = (uint32_t)tris.size(); s->bvhFromCache = cached; s->bvhWidth = bo.width;
         s->hNodes = std::move(bo.nodes);
@@ -761,6 +801,7 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
             if (src && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return false;
             return true;
         };
+        const double tRecords = now();
         if (shade.empty()) shade.resize(12, 0.f);
         const uint32_t mainNodes = (uint32_t)(s->hNodes.size() / 16), mainRefs = (uint32_t)bo.refTri.size();
         s->mainStackNeed = bo.stackNeed; s->bvhParams = bp;
@@ -817,6 +858,9 @@ int mipt_scene_create(mipt_tracer* t, const mipt_scene_desc* d, mipt_scene** out
         s->dev.stackNeed = bo.stackNeed;
         s->dev.emissiveMeshes = count_emissive_meshes(d);
         if (t) hipDeviceSynchronize();
+        if (verbose)
+            fprintf(stderr, "[mipt] scene: %zu triangles, %u nodes (width %u); gather %.0f ms, BVH %s %.0f ms, records + tables %.0f ms, emitters' tree + upload %.0f ms\n",
+                    tris.size(), s->dev.nNodes, bo.width, tGather - tStart, cached ? "from cache" : "build + check", tBuild - tGather, tRecords - tBuild, now() - tRecords);
         *out = s;
         return MIPT_OK;
     });
