@@ -75,6 +75,18 @@ def test_host_only_scene_errors(ptlib):
         ptlib.Scene(None, data, builder=7)
     with pytest.raises(ptlib.MiptError):
         ptlib.Scene(None, data, max_leaf=16)
+    # a mesh large enough for the multi-threaded gather (>= 65 536 triangles): the same refusals from whichever chunk finds them
+    gv, gi = ptlib.grid_mesh(200, 8.0, 1.0, 1)                       # 80 000 triangles
+    for where in (7, len(gi) // 2 + 1, len(gi) - 2):
+        gi2 = gi.copy()
+        gi2[where] = len(gv)
+        with pytest.raises(ptlib.MiptError):
+            ptlib.Scene(None, ptlib.SceneData([(gv, gi2, m)], data.sky), builder=1)
+    gv2 = gv.copy()
+    gv2["position"][len(gv) - 3, 1] = np.nan
+    with pytest.raises(ptlib.MiptError):
+        ptlib.Scene(None, ptlib.SceneData([(gv2, gi, m)], data.sky), builder=1)
+    assert ptlib.Scene(None, ptlib.SceneData([(gv, gi, m)], data.sky), builder=1).bvh_width == 4
 
 
 def test_only_the_permitted_places_touch_the_oracle():
