@@ -189,8 +189,9 @@ uint64_t mipt_scene_get_emitters(const mipt_scene*, float* tris, float* cdf, uin
  * that can change its contribution).  The second tree lies behind the main tree in the device arrays, in the same node layout; this
  * returns it as it lies there (node indices and leaf ranges continue the main tree's: concatenate with mipt_scene_get_bvh's arrays)
  * with its root reference -- an inner node index, or a leaf reference when the emitters fit one leaf; *root_ref = 0: the scene has
- * none (nothing or everything emits, or the tree would not fit the traversal stack / the LDS window the main tree fits).
- * $MIPT_EMITTER_TREE=0 builds none. */
+ * none (nothing or everything emits, the tree would not fit the traversal stack / the LDS window the main tree fits, or -- under a
+ * lit sky, where the ray still has to be walked through the scene -- the emitters are so few (<= 15 triangles) that one more leaf
+ * per ray costs more than stopping at the first hit saves).  $MIPT_EMITTER_TREE=0 builds none, =1 builds it whenever it fits. */
 int mipt_scene_get_emitter_tree(const mipt_scene*, float* nodes, uint32_t* n_nodes, float* refs, uint32_t* n_refs, uint32_t* root_ref);
 
 /* ---- the hot path: PathTracer::Trace (CUDATracer.hpp:352-358; CUDATracerProg.cu:937-963) -------------------
