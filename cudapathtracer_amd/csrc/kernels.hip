@@ -757,6 +757,9 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
     // an emitter that is the closest hit is still found and not occluded, every other outcome adds nothing either way.  The
     // oracle restates it as a counting option (orc_scene_set_emitter_tree), so the roofline counts the work of this algorithm.
     constexpr bool emitFirst = EMIT && !NEE;       // (a template flag: scenes without such a tree run the code they ran before)
+    // ... and where its children can be tested against the emitters at shade time (black sky, emitters in one leaf) the shade
+    // queue is kept sorted by level: see A1
+    const bool lvl = emitFirst ? (skyBlack && (A.S.emitRoot & kLeaf) != 0u) : false;
 
     while (true) {
         const unsigned long long actMask = MIPT_BALLOT(active);
@@ -774,13 +777,21 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
         // reaches its exit.  The capacity the host picks (256 x maxDepth + 256 entries) therefore decides speed, not
         // correctness: a stack a tenth of that size renders the same ray trees (tests: test_small_wave_stack_*).
         bool stalled = false;
-        if (nF >= 64u || (nF > 0u && (starving || (pressure && nF >= nT)))) {
+        const bool wantF = nF >= 64u || (nF > 0u && (starving || (pressure && nF >= nT)));
+        // Batches sorted by level (scenes where children at the last level are tested against the emitters right here, below): in
+        // that mode nothing is ever parked as a terminal record, and the top end of the queue holds the full records whose children
+        // will be at the last level instead.  A batch then comes from one end or the other, so the test runs for every lane of a
+        // batch or for none (mixed, it ran in 96 % of the Cornell box's batches at 45 % of the lanes).
+        const bool wantL = lvl && !wantF && (nT >= 64u || (nT > 0u && (starving || pressure)));
+        if (wantF || wantL) {
             const uint32_t room = (A.cap - sp) / (NEE ? 4u : 2u);
-            uint32_t n = nF < 64u ? nF : 64u;
+            const uint32_t avail = wantL ? nT : nF;
+            uint32_t n = avail < 64u ? avail : 64u;
             if (room < n) { n = room; nShort++; }           // (counted: stats[36] shade batches cut short or put off for lack of room)
             stalled = n == 0u;
         if (!stalled) {
-            nF -= n;
+            uint32_t qbase;                                 // the batch's first queue entry: the n records parked last at that end
+            if (wantL) { qbase = (uint32_t)kSqCap - nT; nT -= n; } else { nF -= n; qbase = nF; }
             MIPT_PROF(pf[6]++; pf[7] += n;)
             const bool has = lane < n;
             Bounce b;
@@ -791,7 +802,7 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
             bool isRefr_ = false;
 #endif
             if (has) {
-                const uint32_t e = nF + lane;
+                const uint32_t e = qbase + lane;
                 v3 P = mk3(sq[0 * kSqCap + e], sq[1 * kSqCap + e], sq[2 * kSqCap + e]);
                 v3 sd = mk3(sq[3 * kSqCap + e], sq[4 * kSqCap + e], sq[5 * kSqCap + e]);
                 v3 sb = mk3(sq[6 * kSqCap + e], sq[7 * kSqCap + e], sq[8 * kSqCap + e]);
@@ -852,28 +863,25 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
             // Not for the light-sampling variants, which are short of registers as it is.
             if constexpr (emitFirst) {
                 // Emitters first, one step earlier.  Children that will be at the last level, under a black sky, in a scene whose
-                // emitters fit one leaf: such a child can only add something if it hits one of those few triangles, so it is
+                // emitters fit one leaf (`lvl`: their records are parked at the queue's top end): such a child can only add something if it hits one of those few triangles, so it is
                 // tested against them here, with the leaf loop's own arithmetic, and a child that hits none of them is counted
                 // as traced and never written to the wave stack (it would be popped, run this very test in its first round and
                 // be retired).  A child that does hit an emitter goes the usual way.
                 bool keep1 = has, keep2 = has;
-                if (skyBlack && (A.S.emitRoot & kLeaf)) {                      // wave-uniform
-                    const bool kidsLast = has && (32u - (uint32_t)__clz((int)(snode * 2u))) >= A.F.maxDepth;
-                    if (MIPT_BALLOT(kidsLast)) {
-                        bool hit1 = false, hit2 = false;
-                        const uint32_t efirst = A.S.emitRoot & 0x07FFFFFFu, ecnt = (A.S.emitRoot >> 27) & 0xFu;
-                        for (uint32_t i = efirst; i < efirst + ecnt; i++) {
-                            float4 ta, tb, tc;
-                            load_ref<LDS_SCENE>(ldsRefs, A.S.refs, i, ta, tb, tc);
-                            hit1 |= mt_hits(b.o1, b.d1, ta, tb, tc);
-                            hit2 |= mt_hits(b.o2, b.d2, ta, tb, tc);
-                        }
-                        if (kidsLast) {
-                            keep1 = hit1; keep2 = hit2;
-                            const uint32_t gone = (hit1 ? 0u : 1u) + (hit2 ? 0u : 1u);
-                            traced += gone;
-                            if (A.pixelRays && gone) atomicAdd(A.pixelRays + spix, gone);
-                        }
+                if (wantL) {                  // (wave-uniform: a batch from the queue's top end, every record's children are at the last level)
+                    bool hit1 = false, hit2 = false;
+                    const uint32_t efirst = A.S.emitRoot & 0x07FFFFFFu, ecnt = (A.S.emitRoot >> 27) & 0xFu;
+                    for (uint32_t i = efirst; i < efirst + ecnt; i++) {
+                        float4 ta, tb, tc;
+                        load_ref<LDS_SCENE>(ldsRefs, A.S.refs, i, ta, tb, tc);
+                        hit1 |= mt_hits(b.o1, b.d1, ta, tb, tc);
+                        hit2 |= mt_hits(b.o2, b.d2, ta, tb, tc);
+                    }
+                    if (has) {
+                        keep1 = hit1; keep2 = hit2;
+                        const uint32_t gone = (hit1 ? 0u : 1u) + (hit2 ? 0u : 1u);
+                        traced += gone;
+                        if (A.pixelRays && gone) atomicAdd(A.pixelRays + spix, gone);
                     }
                 }
                 const bool takeOwn = keep2 && !active;
@@ -951,7 +959,7 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
         }
         }
         // ---- A2. a batch of terminal records: miss radiance, or the emission of a hit at the last level -------------
-        if (nT >= 64u || (nT > 0u && (starving || pressure))) {
+        if (!lvl && (nT >= 64u || (nT > 0u && (starving || pressure)))) {
             const uint32_t n = nT < 64u ? nT : 64u;
             MIPT_PROF(pf[8]++; pf[9] += n;)
             if (lane < n) {
@@ -1047,7 +1055,7 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
             if (nF + nT == 0u) break;
             if (stalled) {          // nothing in flight and no room to shade into: a stack smaller than one record's children
                 if (lane == 0) atomicOr(A.stats + 39, 1ull);
-                nF -= nF < 64u ? nF : 64u;
+                if (nF || !lvl) nF -= nF < 64u ? nF : 64u; else nT -= nT < 64u ? nT : 64u;       // (level-sorted mode: both ends hold full records)
             }
             continue;
         }
@@ -1269,15 +1277,26 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
                 const bool dead = h.tri < 0 ? (!shadow && (skyBlack || (NEE && (pix & kNoEnvBit))))
                                             : (shadow || !(__float_as_uint(h.u) >> 31) || (NEE && (pix & kNoEmitBit)));
                 if (dead) { active = false; fin = false; }
+                else if (lvl) {
+                    // level-sorted mode (A1): a terminal record that is not dead is a last-level ray whose closest hit emits (the sky
+                    // is black).  There are few of them; its emission is added here, so that the queue's top end is free for the
+                    // records whose children will be at the last level
+                    const uint32_t mesh = __float_as_uint(A.S.shade[(size_t)h.tri * 3].w);
+                    Material mat = load_material(A.S, mesh);
+                    add_sample(A.sample, pix, beta * (mat.emissive * mat.emissiveStrength));
+                    active = false; fin = false;
+                }
             }
             moved = (uint32_t)__popcll(fm);
             fm = MIPT_BALLOT(fin);
             moved -= (uint32_t)__popcll(fm);          // retired on the spot
             // no room: stay terminated-but-unparked until the queue has been drained
             fin = fin && nF + nT + (uint32_t)__popcll(fm & below) < (uint32_t)kSqCap;
-            const unsigned long long mF = MIPT_BALLOT(fin && !term), mT = MIPT_BALLOT(fin && term);
+            // which end of the queue: terminal records at the top -- or, in level-sorted mode, the records whose children will be at the last level
+            const bool top = lvl ? level + 2u >= A.F.maxDepth : term;
+            const unsigned long long mF = MIPT_BALLOT(fin && !top), mT = MIPT_BALLOT(fin && top);
             if (fin) {
-                const uint32_t e = term ? (uint32_t)kSqCap - 1u - (nT + (uint32_t)__popcll(mT & below)) : nF + (uint32_t)__popcll(mF & below);
+                const uint32_t e = top ? (uint32_t)kSqCap - 1u - (nT + (uint32_t)__popcll(mT & below)) : nF + (uint32_t)__popcll(mF & below);
                 v3 P = o + d * h.t;                                   // tail of NearestIntersectSubset (:294)
                 sq[0 * kSqCap + e] = P.x; sq[1 * kSqCap + e] = P.y; sq[2 * kSqCap + e] = P.z;
                 sq[3 * kSqCap + e] = d.x; sq[4 * kSqCap + e] = d.y; sq[5 * kSqCap + e] = d.z;
@@ -1292,7 +1311,7 @@ __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavesta
         }
         if (stuck && moved == 0u) {       // overflow: the children of one batch are lost, the host reports it, nothing is written past the stack
             if (lane == 0) atomicOr(A.stats + 39, 1ull);
-            nF -= nF < 64u ? nF : 64u;
+            if (nF || !lvl) nF -= nF < 64u ? nF : 64u; else nT -= nT < 64u ? nT : 64u;
         }
     }
     // one counter update per wave
