@@ -500,7 +500,8 @@ class Tracer:
         return out
 
     def test_rcp_sweep(self, steps):
-        """(compared, differing, first differing input bits, differing by > 1 ulp) of rcp_newton<steps> vs 1.0f / x"""
+        """(compared, differing, first differing input bits, differing by > 1 ulp) of rcp_newton<steps> vs 1.0f / x;
+        steps = 4: of sqrt_unit vs sqrtf"""
         out = (C.c_uint64 * 4)()
         self._chk(lib.mipt_test_rcp_sweep(self.h, steps, out), "test_rcp_sweep")
         return tuple(int(v) for v in out)

@@ -1620,10 +1620,11 @@ int mipt_test_issue(mipt_tracer* t, int packed, uint32_t blocks_per_cu, uint32_t
 
 // Exhaustive comparison of the integrator's short reciprocal (device_math.h rcp_newton<steps>) with the compiler's IEEE
 // division over every float of magnitude 2^-100 .. 2^100.  out[0] compared, out[1] differing, out[2] first differing input
-// (bits, or 0), out[3] differing by more than one unit in the last place.
+// (bits, or 0), out[3] differing by more than one unit in the last place.  steps = 4: the same for the sampler's short square
+// root (device_math.h sqrt_unit) against sqrtf, over zero and every positive float in 2^-96 .. 2^100.
 int mipt_test_rcp_sweep(mipt_tracer* t, int steps, uint64_t out[4]) {
     return guarded(t, [&]() -> int {
-        if (!t || !out || steps < 0 || steps > 3) return fail(t, MIPT_E_INVALID, "test_rcp_sweep: steps 0..3");
+        if (!t || !out || steps < 0 || steps > 4) return fail(t, MIPT_E_INVALID, "test_rcp_sweep: steps 0..3, or 4 for the square root");
         if (use(t)) return MIPT_E_HIP;
         unsigned long long* d = nullptr;
         struct Cleanup { unsigned long long*& d; ~Cleanup() { if (d) hipFree(d); } } cleanup{ d };

@@ -310,27 +310,35 @@ MIPT_DEV void cone_basis(v3 dir, v3& right, v3& up) {
     right = rlen <= 0 ? mk3(0, 0, 1) : mk3(rx / rlen, 0.f, ry / rlen);      // (0 / rlen is +0 for rlen > 0: no division spent on it)
     up = cross3(right, dir);
 }
-MIPT_DEV v3 rand_dir_inside_cone(Lcg& rng, v3 dir, float size) {
-    v3 right, up; cone_basis(dir, right, up);
+// (the basis comes from the caller: one bounce draws twice about the same normal, and the compiler did not share the two
+//  inlined copies of cone_basis across the opacity branch -- a square root and two divisions per shaded hit)
+MIPT_DEV v3 rand_dir_inside_cone(Lcg& rng, v3 dir, v3 right, v3 up, float size) {
     float u = rng.NextFloat(), v = rng.NextFloat();
     float theta = (float)(6.283185307179586 * (double)u);
     float sx = 1 - 2 * v * size;
     float sn, cs; det_sincosf(theta, &sn, &cs);
-    float sy = __builtin_sqrtf(1 - sx * sx) * cs;
-    float sz = __builtin_sqrtf(1 - sx * sx) * sn;
+    float sy = sqrt_unit(1 - sx * sx) * cs;
+    float sz = sqrt_unit(1 - sx * sx) * sn;
+    return sx * dir + sy * up + sz * right;
+}
+MIPT_DEV v3 rand_dir_inside_cone(Lcg& rng, v3 dir, float size) {
+    v3 right, up; cone_basis(dir, right, up);
+    return rand_dir_inside_cone(rng, dir, right, up, size);
+}
+MIPT_DEV v3 ggx_rand_dir_inside_cone(Lcg& rng, v3 dir, v3 right, v3 up, float size) {
+    float u = rng.NextFloat(), v = rng.NextFloat();
+    float theta = (float)(6.283185307179586 * (double)u);
+    float phi = det_atan2f(size * sqrt_unit(v), sqrt_unit(1 - v));
+    float sp, cp; det_sincosf(phi, &sp, &cp);
+    float sx = 1 - sp;                                        // (sic) CUDATracerProg.cu:160
+    float sn, cs; det_sincosf(theta, &sn, &cs);
+    float sy = sqrt_unit(1 - sx * sx) * cs;
+    float sz = sqrt_unit(1 - sx * sx) * sn;
     return sx * dir + sy * up + sz * right;
 }
 MIPT_DEV v3 ggx_rand_dir_inside_cone(Lcg& rng, v3 dir, float size) {
     v3 right, up; cone_basis(dir, right, up);
-    float u = rng.NextFloat(), v = rng.NextFloat();
-    float theta = (float)(6.283185307179586 * (double)u);
-    float phi = det_atan2f(size * __builtin_sqrtf(v), __builtin_sqrtf(1 - v));
-    float sp, cp; det_sincosf(phi, &sp, &cp);
-    float sx = 1 - sp;                                        // (sic) CUDATracerProg.cu:160
-    float sn, cs; det_sincosf(theta, &sn, &cs);
-    float sy = __builtin_sqrtf(1 - sx * sx) * cs;
-    float sz = __builtin_sqrtf(1 - sx * sx) * sn;
-    return sx * dir + sy * up + sz * right;
+    return ggx_rand_dir_inside_cone(rng, dir, right, up, size);
 }
 
 // ---- estimator 2 (include/mipt.h): the same two lobes sampled the textbook way ------------------------------------
@@ -421,7 +429,9 @@ template <bool PBS = false>      // PBS: estimator 2
 MIPT_DEV Bounce shade_hit(const Material& mat, const Surface& sf, v3 d, bool front, Lcg& rng) {
     Bounce b;
     v3 N = sf.N, P = sf.P;
-    v3 mN = PBS ? ggx_visible_normal(rng, N, d, mat.roughness) : ggx_rand_dir_inside_cone(rng, N, mat.roughness);
+    v3 right, up;
+    if constexpr (!PBS) cone_basis(N, right, up);
+    v3 mN = PBS ? ggx_visible_normal(rng, N, d, mat.roughness) : ggx_rand_dir_inside_cone(rng, N, right, up, mat.roughness);
     v3 R = reflect3(d, mN);
     b.o1 = P + N * 1e-6f; b.d1 = R;
     float n1 = 1.f, n2 = mat.n; n2 += FLT_EPSILON;
@@ -448,7 +458,7 @@ MIPT_DEV Bounce shade_hit(const Material& mat, const Surface& sf, v3 d, bool fro
         b.d2 = normalize3(front_refr + down * drl);
         b.o2 = P - N * 1e-6f;
     } else {
-        b.d2 = PBS ? cosine_dir_about(rng, N) : rand_dir_inside_cone(rng, N, 0.49f);
+        b.d2 = PBS ? cosine_dir_about(rng, N) : rand_dir_inside_cone(rng, N, right, up, 0.49f);
         b.o2 = P + N * 1e-6f;
     }
     b.f2 = mat.color * rt * ((mat.opacity == 1.f) ? 1.f : (1 - mat.opacity));

@@ -92,7 +92,27 @@ __global__ void __launch_bounds__(256) k_test_rcp_sweep(unsigned long long* out)
     }
     atomicAdd(out + 0, n); if (bad) atomicAdd(out + 1, bad); if (worse) atomicAdd(out + 3, worse);
 }
+// The same for sqrt_unit against sqrtf: zero and every positive float in [2^-96, 2^100].
+__global__ void __launch_bounds__(256) k_test_sqrt_sweep(unsigned long long* out) {
+    unsigned long long n = 0, bad = 0, worse = 0;
+    const uint32_t stride = gridDim.x * 256u;
+    for (unsigned long long p = blockIdx.x * 256u + threadIdx.x; p < (1ull << 31); p += stride) {
+        const uint32_t bits = (uint32_t)p, ex = (bits >> 23) & 0xFFu;
+        if (bits != 0u && (ex < 31u || ex > 227u)) continue;
+        const float x = __uint_as_float(bits);
+        const float want = __builtin_sqrtf(x), got = sqrt_unit(x);
+        n++;
+        if (__float_as_uint(want) != __float_as_uint(got)) {
+            bad++;
+            const int du = (int)__float_as_uint(want) - (int)__float_as_uint(got);
+            if (du > 1 || du < -1) worse++;
+            atomicMin(out + 2, (unsigned long long)bits | (1ull << 40));
+        }
+    }
+    atomicAdd(out + 0, n); if (bad) atomicAdd(out + 1, bad); if (worse) atomicAdd(out + 3, worse);
+}
 void launch_test_rcp_sweep(int steps, int blocks, unsigned long long* out, hipStream_t s) {
+    if (steps == 4) { hipLaunchKernelGGL(k_test_sqrt_sweep, dim3(blocks), dim3(256), 0, s, out); return; }
     if (steps == 0) hipLaunchKernelGGL(k_test_rcp_sweep<0>, dim3(blocks), dim3(256), 0, s, out);      // the bare estimate: shows the sweep can see a difference
     else if (steps == 1) hipLaunchKernelGGL(k_test_rcp_sweep<1>, dim3(blocks), dim3(256), 0, s, out);
     else if (steps == 2) hipLaunchKernelGGL(k_test_rcp_sweep<2>, dim3(blocks), dim3(256), 0, s, out);

@@ -308,7 +308,9 @@ typedef struct {
 /* Exhaustive check of the integrator's short reciprocal (rcp + `steps` Newton corrections in FMA form, used for a ray's
  * inverse direction and the triangle test's 1 / det) against IEEE division over every float of magnitude 2^-100 .. 2^100:
  * out[0] = values compared, out[1] = values whose bits differ, out[2] = first differing input (bits), out[3] = differing
- * by more than one unit in the last place.  (No counterpart in the reference.) */
+ * by more than one unit in the last place.  steps = 4 runs the same comparison for the sampler's short square root (the IEEE
+ * expansion without the rescaling that only inputs below 2^-96 need) against sqrtf, over zero and every positive float in
+ * 2^-96 .. 2^100.  (No counterpart in the reference.) */
 int  mipt_test_rcp_sweep(mipt_tracer*, int steps, uint64_t out[4]);
 int  mipt_test_issue(mipt_tracer*, int packed, uint32_t blocks_per_cu, uint32_t iters, mipt_issue_result* out);
 
