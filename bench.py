@@ -147,7 +147,7 @@ def dbg(msg):
 def source_sha16():
     """Hash of the kernel + host sources: PMC figures measured on another build are not attached to this one."""
     h = hashlib.sha256()
-    for f in ("kernels.hip", "kernels.h", "device_math.h", "api.hip", "bvh_builder.cpp"):
+    for f in ("kernels.hip", "wavestack_kernel.inc", "kernels.h", "device_math.h", "api.hip", "bvh_builder.cpp"):
         with open(os.path.join(ROOT, "cudapathtracer_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

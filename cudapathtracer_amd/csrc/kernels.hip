@@ -695,6 +695,15 @@ MIPT_DEV uint32_t wave_sum_u32(uint32_t v) { for (int s = 32; s > 0; s >>= 1) v 
 #else
 #define MIPT_PROF(x)
 #endif
+// Phase clock (make variant NAME=phasetime EXTRA="-DMIPT_LANE_PROFILE -DMIPT_EXP_PHASETIME", scripts/exp_phase_time.py): the
+// wave's s_memtime ticks since the previous mark go to phase k; the sums take the places of stats[8..13], [15] and [17] --
+// 0 full shade batches, 1 terminal batches, 2 the end-of-frame check, 3 node loop, 4 leaf loop and the end-of-leaf rule, 5 parking,
+// 6 the refill, 7 the loop top (batch decisions).
+#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_PHASETIME)
+#define MIPT_PT(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt_[k] += now_ - ptLast_; ptLast_ = now_; }
+#else
+#define MIPT_PT(k)
+#endif
 
 #define MIPT_BALLOT(x) __builtin_amdgcn_ballot_w64(x)      // wave64 mask of a per-lane predicate
 // Threads per persistent block.  A block's CU slot is only handed to the next frame's blocks when all its waves have ended, so
@@ -706,633 +715,15 @@ template <bool LDS_SCENE> struct WaveStackBlock { static constexpr int value = L
 // like (no spills) run 0.85x; five at 96 VGPRs and 32 KiB of LDS per 256 threads spill 35-40 registers, 0.6-0.7x.
 template <bool LDS_SCENE, bool WIDE, bool NEE, bool PBS = false, bool EMIT = false>      // EMIT: the scene has an emitters' tree ("emitters first", below)
 __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavestack(StackArgs A) {       // (hipcc: second argument = minimum waves per SIMD)
-    constexpr int kBlock = WaveStackBlock<LDS_SCENE>::value;       // shadows the file-wide block size inside this kernel
-    constexpr int kStackStride = kBlock;
-    constexpr int kSqCap = SqCap<LDS_SCENE>::value;
-    constexpr bool kShortRcp = true;       // 3-instruction reciprocals for the rays this kernel generates itself (ray_pre, mt_test): +2-3 %
-    __shared__ uint32_t ldsStack[(LDS_SCENE ? kLdsSceneStack + 1 : kLdsStack) * kBlock];
-    __shared__ float sqMem[(kBlock / 64) * kSqWords * kSqCap];
-    __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneVec : 1];
-    if (LDS_SCENE) {
-        const uint32_t nn = A.S.nNodes * 4, nr = A.S.nRefs * 3;
-        for (uint32_t i = threadIdx.x; i < nn; i += kBlock) ldsScene[i] = A.S.nodes[i];
-        for (uint32_t i = threadIdx.x; i < nr; i += kBlock) ldsScene[nn + i] = A.S.refs[i];
-        __syncthreads();
-    }
-    const float4* ldsNodes = ldsScene;
-    const float4* ldsRefs = ldsScene + (LDS_SCENE ? A.S.nNodes * 4 : 0);
-    const uint32_t lane = __lane_id();
-    const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + wv;
-    const size_t wbase = (size_t)wave * A.cap;
-    float4* __restrict__ qa = A.stack.a + wbase;
-    float4* __restrict__ qb = A.stack.b + wbase;
-    float4* __restrict__ qc = A.stack.c + wbase;
-    float* sq = sqMem + wv * (kSqWords * kSqCap);
-    uint32_t* sqi = reinterpret_cast<uint32_t*>(sq);
-    const unsigned long long below = (1ull << lane) - 1ull;
-
-    // wave-uniform state
-    uint32_t sp = 0;
-    uint32_t nF = 0, nT = 0;          // parked records: "full" ones (will spawn children) fill the queue from slot 0 up,
-                                      // "terminal" ones (miss, or hit at the last level: emission only) from the top down
-    bool more = true;
-    uint32_t curBand = blockIdx.x & 7u, bandsDry = 0;                 // xcdBands: the band this wave claims from now
-    const uint32_t bandLen = ((A.npix + 7u) / 8u + 63u) & ~63u;
-    // per-lane traversal state
-    bool active = false;
-    v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), beta = mk3(0, 0, 0);
-    uint32_t pix = 0, node = 1, s0 = 0;
-    RayPre r = ray_pre<false>(o, d);
-    HitRec h; h.t = __builtin_inff(); h.u = h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
-    uint32_t cur = kTerm;
-    uint32_t* const lstk = ldsStack + threadIdx.x;
-    uint32_t deep[LDS_SCENE ? 1 : (WIDE ? kWideStackCap : kStackCap) - kLdsStack];
-    int tsp = 0;
-    uint32_t traced = 0, shadowTraced = 0;
-    uint32_t nShort = 0;              // wave-uniform
-    MIPT_PROF(unsigned long long pf[12] = {};)
-    // Work that cannot change the image is not done (the rays are still traced and counted):
-    //  * a ray that ends (miss, or hit at the last level) without anything to add -- black analytic sky, non-emitting
-    //    surface, flagged-off term of the light-sampling estimators -- is retired on the spot instead of being parked in
-    //    the shade queue and run through a terminal batch (in a full binary tree half of all rays are at the last level);
-    //  * in a scene without emitting meshes a last-level ray only needs hit-or-miss: it stops at its first triangle hit.
-    // (the "emits" flag of the closest triangle so far rides in the sign bit of h.u -- u >= 0 -- so it costs no register)
-    const bool skyBlack = A.S.env == nullptr && A.S.skyIntensity == 0.f;
-    // Emitters first.  A last-level ray can only add emission (or the sky, if it escapes): what it needs is "is the closest hit an
-    // emitter", not the closest hit.  In a scene with emitting meshes it therefore walks the small tree of the emitting
-    // triangles first (SceneDev::emitRoot) -- the main tree's root waits on its stack -- and then the main tree with the
-    // distance found as its bound, where the first hit on anything that does not emit ends it (it is occluded, or there was no
-    // emitter to begin with); under a black sky a ray that found no emitter never enters the main tree at all.  Same image:
-    // an emitter that is the closest hit is still found and not occluded, every other outcome adds nothing either way.  The
-    // oracle restates it as a counting option (orc_scene_set_emitter_tree), so the roofline counts the work of this algorithm.
-    constexpr bool emitFirst = EMIT && !NEE;       // (a template flag: scenes without such a tree run the code they ran before)
-    // ... and where its children can be tested against the emitters at shade time (black sky, emitters in one leaf) the shade
-    // queue is kept sorted by level: see A1
-    const bool lvl = emitFirst ? (skyBlack && (A.S.emitRoot & kLeaf) != 0u) : false;
-
-    while (true) {
-        const unsigned long long actMask = MIPT_BALLOT(active);
-        const uint32_t idle = 64u - (uint32_t)__popcll(actMask);
-        const bool starving = idle >= A.refill && sp == 0 && !more;
-        const bool pressure = nF + nT > (uint32_t)kSqCap - 32u;      // little room left for rays that terminate next
-
-        // ---- A1. shade a batch of "full" records: every lane runs the whole bounce and pushes two children ----------
-        // A batch never pushes past the wave's stack: it shades as many records as the stack has room for the children of
-        // (two per record, four with light sampling), and none -- the wave is then `stalled` -- when there is no room at
-        // all.  A stalled wave goes on with everything that frees room: terminal batches, refills (from one idle lane on),
-        // traversal, parking.  Only when none of those can move either -- stack full, shade queue full of records that want
-        // to spawn, every lane holding a finished ray it cannot park -- is there nothing left to wait for: that one state
-        // drops a batch's children and raises the overflow flag (mipt_synchronize: MIPT_E_LIMIT), so every wave still
-        // reaches its exit.  The capacity the host picks (256 x maxDepth + 256 entries) therefore decides speed, not
-        // correctness: a stack a tenth of that size renders the same ray trees (tests: test_small_wave_stack_*).
-        bool stalled = false;
-        const bool wantF = nF >= 64u || (nF > 0u && (starving || (pressure && nF >= nT)));
-        // Batches sorted by level (scenes where children at the last level are tested against the emitters right here, below): in
-        // that mode nothing is ever parked as a terminal record, and the top end of the queue holds the full records whose children
-        // will be at the last level instead.  A batch then comes from one end or the other, so the test runs for every lane of a
-        // batch or for none (mixed, it ran in 96 % of the Cornell box's batches at 45 % of the lanes).
-        const bool wantL = lvl && !wantF && (nT >= 64u || (nT > 0u && (starving || pressure)));
-        if (wantF || wantL) {
-            const uint32_t room = (A.cap - sp) / (NEE ? 4u : 2u);
-            const uint32_t avail = wantL ? nT : nF;
-            uint32_t n = avail < 64u ? avail : 64u;
-            if (room < n) { n = room; nShort++; }           // (counted: stats[36] shade batches cut short or put off for lack of room)
-            stalled = n == 0u;
-        if (!stalled) {
-            uint32_t qbase;                                 // the batch's first queue entry: the n records parked last at that end
-            if (wantL) { qbase = (uint32_t)kSqCap - nT; nT -= n; } else { nF -= n; qbase = nF; }
-            MIPT_PROF(pf[6]++; pf[7] += n;)
-            const bool has = lane < n;
-            Bounce b;
-            uint32_t spix = 0, snode = 0, ss0 = 0;
-            bool wantEnv = false, wantEmit = false, opaque = false;
-            v3 sdir = mk3(0, 0, 1), scon = mk3(0, 0, 0), edir = mk3(0, 0, 1), econ = mk3(0, 0, 0); float etmax = 0.f;
-#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_CLASSCOUNT)
-            bool isRefr_ = false;
-#endif
-            if (has) {
-                const uint32_t e = qbase + lane;
-                v3 P = mk3(sq[0 * kSqCap + e], sq[1 * kSqCap + e], sq[2 * kSqCap + e]);
-                v3 sd = mk3(sq[3 * kSqCap + e], sq[4 * kSqCap + e], sq[5 * kSqCap + e]);
-                v3 sb = mk3(sq[6 * kSqCap + e], sq[7 * kSqCap + e], sq[8 * kSqCap + e]);
-                const uint32_t fpix = sqi[9 * kSqCap + e];
-                spix = fpix & (NEE ? kPixMask : 0xFFFFFFFFu); snode = sqi[10 * kSqCap + e]; ss0 = sqi[11 * kSqCap + e];
-                const float su = sq[12 * kSqCap + e], sv = sq[13 * kSqCap + e];
-                const uint32_t tf = sqi[14 * kSqCap + e];
-                const bool front = (tf >> 31) != 0;
-                const uint32_t tri = tf & 0x7FFFFFFFu;
-                const float4* Sh = A.S.shade + (size_t)tri * 3;
-                float4 n0 = Sh[0], n1 = Sh[1], n2 = Sh[2];
-                float w0 = 1 - su - sv, w1 = su, w2 = sv;
-                v3 hn = xyz(n0) * w0 + xyz(n1) * w1 + xyz(n2) * w2;
-                Surface sf; sf.P = P; sf.N = front ? hn : -hn; sf.mesh = __float_as_uint(n0.w);
-                Material mat = load_material(A.S, sf.mesh);
-#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_CLASSCOUNT)
-                isRefr_ = mat.opacity < 1.f;
-#endif
-                if (!(NEE && (fpix & kNoEmitBit))) add_sample(A.sample, spix, sb * (mat.emissive * mat.emissiveStrength));
-                Lcg rng; rng.state = node_seed(ss0, snode);
-                b = shade_hit<PBS>(mat, sf, sd, front, rng);
-                b.f1 = sb * b.f1; b.f2 = sb * b.f2;
-                if constexpr (NEE) {
-                    // what the diffuse child would find by chance -- the environment when it escapes, the emission of the
-                    // surface it lands on -- is sampled explicitly: further draws of this hit's stream (2 for the env map,
-                    // then 3 for the emitters), one occlusion ray each; the child is flagged to skip those terms itself
-                    opaque = mat.opacity == 1.f;
-                    constexpr float minCos = PBS ? 0.f : 0.02f;        // estimator 3: the cosine lobe covers the whole hemisphere
-                    if (opaque && A.S.envCdf) {
-                        const float u1 = rng.NextFloat(), u2 = rng.NextFloat();
-                        v3 L; float wgt;
-                        if (sample_env(A.S, u1, u2, sdir, L, wgt) && dot3(sdir, sf.N) > minCos) {
-                            if constexpr (PBS) wgt = wgt * (dot3(sdir, sf.N) * 1.96f);     // (cos / pi) / p_cap: the lobe's density instead of the cap's
-                            wantEnv = true; scon = b.f2 * (L * wgt);
-                        }
-                    }
-                    if (opaque && A.S.nEmit) {
-                        const float r0 = rng.NextFloat(), r1 = rng.NextFloat(), r2 = rng.NextFloat();
-                        v3 Lw;
-                        if (sample_emitter(A.S, r0, r1, r2, b.o2, sf.N, minCos, edir, Lw, etmax)) {
-                            if constexpr (PBS) Lw = Lw * (dot3(edir, sf.N) * 1.96f);
-                            wantEmit = true; econ = b.f2 * Lw;
-                        }
-                    }
-                }
-            }
-#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_CLASSCOUNT)
-            {   // shade batches that hold both material classes (-> stats[18]) and refractive records (-> stats[19]); they take the refill counters' slots
-                const unsigned long long hm_ = MIPT_BALLOT(has), rm_ = MIPT_BALLOT(isRefr_);
-                pf[10] += (rm_ != 0ull && rm_ != hm_) ? 1u : 0u; pf[11] += (uint32_t)__popcll(rm_);
-            }
-#endif
-            const unsigned long long sm = NEE ? MIPT_BALLOT(wantEnv) : 0ull, em = NEE ? MIPT_BALLOT(wantEmit) : 0ull;
-            const uint32_t nEnvRays = (uint32_t)__popcll(sm);
-            // Hand-off: a lane without a ray keeps the second child of the record it has just shaded, so that child makes no
-            // trip through the wave stack (throughput unchanged; HBM traffic per Cornell frame 8.6 -> 4.9 GB, most of it
-            // write-backs of stack lines that were dead by the time they were evicted: profiles/r2/exp_handoff.log).
-            // Not for the light-sampling variants, which are short of registers as it is.
-            if constexpr (emitFirst) {
-                // Emitters first, one step earlier.  Children that will be at the last level, under a black sky, in a scene whose
-                // emitters fit one leaf (`lvl`: their records are parked at the queue's top end): such a child can only add something if it hits one of those few triangles, so it is
-                // tested against them here, with the leaf loop's own arithmetic, and a child that hits none of them is counted
-                // as traced and never written to the wave stack (it would be popped, run this very test in its first round and
-                // be retired).  A child that does hit an emitter goes the usual way.
-                bool keep1 = has, keep2 = has;
-                if (wantL) {                  // (wave-uniform: a batch from the queue's top end, every record's children are at the last level)
-                    bool hit1 = false, hit2 = false;
-                    const uint32_t efirst = A.S.emitRoot & 0x07FFFFFFu, ecnt = (A.S.emitRoot >> 27) & 0xFu;
-                    for (uint32_t i = efirst; i < efirst + ecnt; i++) {
-                        float4 ta, tb, tc;
-                        load_ref<LDS_SCENE>(ldsRefs, A.S.refs, i, ta, tb, tc);
-                        hit1 |= mt_hits(b.o1, b.d1, ta, tb, tc);
-                        hit2 |= mt_hits(b.o2, b.d2, ta, tb, tc);
-                    }
-                    if (has) {
-                        keep1 = hit1; keep2 = hit2;
-                        const uint32_t gone = (hit1 ? 0u : 1u) + (hit2 ? 0u : 1u);
-                        traced += gone;
-                        if (A.pixelRays && gone) atomicAdd(A.pixelRays + spix, gone);
-                    }
-                }
-                const bool takeOwn = keep2 && !active;
-                const bool push2 = keep2 && !takeOwn;
-                const unsigned long long k1 = MIPT_BALLOT(keep1), k2 = MIPT_BALLOT(push2);
-                const uint32_t w = sp + (uint32_t)__popcll(k1 & below) + (uint32_t)__popcll(k2 & below);
-                if (keep1) {
-                    stack_store(&qa[w], make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x));
-                    stack_store(&qb[w], make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y));
-                    stack_store(&qc[w], make_float4(b.f1.z, __uint_as_float(spix), __uint_as_float(snode * 2u), __uint_as_float(ss0)));
-                }
-                if (push2) {
-                    const uint32_t w2 = w + (keep1 ? 1u : 0u);
-                    stack_store(&qa[w2], make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x));
-                    stack_store(&qb[w2], make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y));
-                    stack_store(&qc[w2], make_float4(b.f2.z, __uint_as_float(spix), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0)));
-                }
-                if (takeOwn) {
-                    o = b.o2; d = b.d2; beta = b.f2; pix = spix; node = snode * 2u + 1u; s0 = ss0;
-                    r = ray_pre<kShortRcp>(o, d);
-                    h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
-                    tsp = 0;
-                    if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, kTerm); else MIPT_STACK_PUSH(lstk, deep, tsp, kTerm);
-                    cur = 0; active = true; traced++;
-                    if ((32u - (uint32_t)__clz((int)node)) >= A.F.maxDepth) {     // last level: the emitters' tree first
-                        if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, 0u); else MIPT_STACK_PUSH(lstk, deep, tsp, 0u);
-                        cur = A.S.emitRoot;
-                    }
-                    if (A.pixelRays) atomicAdd(A.pixelRays + pix, 1u);
-                }
-                sp += (uint32_t)__popcll(k1) + (uint32_t)__popcll(k2);          // (<= 2 n: within the room the batch was sized for)
-                continue;
-            }
-            const bool takeOwn = !NEE && has && !active;
-            const unsigned long long tk = NEE ? 0ull : MIPT_BALLOT(takeOwn);
-            const uint32_t total = 2u * n + nEnvRays + (uint32_t)__popcll(em) - (uint32_t)__popcll(tk);
-            {       // (sp + total <= cap by the choice of n)
-                if (has) {
-                    const uint32_t w = sp + 2u * lane - (uint32_t)__popcll(tk & below);
-                    uint32_t flags2 = 0;
-                    if (NEE && opaque) flags2 = (A.S.envCdf ? kNoEnvBit : 0u) | (A.S.nEmit ? kNoEmitBit : 0u);
-                    stack_store(&qa[w], make_float4(b.o1.x, b.o1.y, b.o1.z, b.d1.x));
-                    stack_store(&qb[w], make_float4(b.d1.y, b.d1.z, b.f1.x, b.f1.y));
-                    stack_store(&qc[w], make_float4(b.f1.z, __uint_as_float(spix), __uint_as_float(snode * 2u), __uint_as_float(ss0)));
-                    if (takeOwn) {
-                        o = b.o2; d = b.d2; beta = b.f2; pix = spix; node = snode * 2u + 1u; s0 = ss0;
-                        r = ray_pre<kShortRcp>(o, d);
-                        h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
-                        tsp = 0;
-                        if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, kTerm); else MIPT_STACK_PUSH(lstk, deep, tsp, kTerm);
-                        cur = 0; active = true; traced++;
-                        if (A.pixelRays) atomicAdd(A.pixelRays + pix, 1u);
-                    } else {
-                        stack_store(&qa[w + 1], make_float4(b.o2.x, b.o2.y, b.o2.z, b.d2.x));
-                        stack_store(&qb[w + 1], make_float4(b.d2.y, b.d2.z, b.f2.x, b.f2.y));
-                        stack_store(&qc[w + 1], make_float4(b.f2.z, __uint_as_float(spix | flags2), __uint_as_float(snode * 2u + 1u), __uint_as_float(ss0)));
-                    }
-                }
-                // occlusion rays: the record's node word carries tmax (+inf towards the environment)
-                if (NEE && wantEnv) {
-                    const uint32_t w = sp + 2u * n + (uint32_t)__popcll(sm & below);
-                    stack_store(&qa[w], make_float4(b.o2.x, b.o2.y, b.o2.z, sdir.x));
-                    stack_store(&qb[w], make_float4(sdir.y, sdir.z, scon.x, scon.y));
-                    stack_store(&qc[w], make_float4(scon.z, __uint_as_float(spix | kShadowBit), __builtin_inff(), __uint_as_float(ss0)));
-                }
-                if (NEE && wantEmit) {
-                    const uint32_t w = sp + 2u * n + nEnvRays + (uint32_t)__popcll(em & below);
-                    stack_store(&qa[w], make_float4(b.o2.x, b.o2.y, b.o2.z, edir.x));
-                    stack_store(&qb[w], make_float4(edir.y, edir.z, econ.x, econ.y));
-                    stack_store(&qc[w], make_float4(econ.z, __uint_as_float(spix | kShadowBit), etmax, __uint_as_float(ss0)));
-                }
-                sp += total;
-            }
-            continue;
-        }
-        }
-        // ---- A2. a batch of terminal records: miss radiance, or the emission of a hit at the last level -------------
-        if (!lvl && (nT >= 64u || (nT > 0u && (starving || pressure)))) {
-            const uint32_t n = nT < 64u ? nT : 64u;
-            MIPT_PROF(pf[8]++; pf[9] += n;)
-            if (lane < n) {
-                const uint32_t e = (uint32_t)kSqCap - nT + lane;
-                v3 sd = mk3(sq[3 * kSqCap + e], sq[4 * kSqCap + e], sq[5 * kSqCap + e]);
-                v3 sb = mk3(sq[6 * kSqCap + e], sq[7 * kSqCap + e], sq[8 * kSqCap + e]);
-                const uint32_t fpix = sqi[9 * kSqCap + e], spix = fpix & (NEE ? kPixMask : 0xFFFFFFFFu);
-                const bool shadow = NEE && (fpix & kShadowBit), noEnv = NEE && (fpix & kNoEnvBit);
-                const uint32_t tf = sqi[14 * kSqCap + e];
-                if (tf == 0xFFFFFFFFu) {
-                    if (shadow) add_sample(A.sample, spix, sb);                  // unoccluded: the pre-weighted environment term
-                    else if (!noEnv) add_sample(A.sample, spix, sb * on_miss(A.S, sd));
-                } else if (!shadow && !(NEE && (fpix & kNoEmitBit))) {
-                    const uint32_t mesh = __float_as_uint(A.S.shade[(size_t)(tf & 0x7FFFFFFFu) * 3].w);
-                    Material mat = load_material(A.S, mesh);
-                    add_sample(A.sample, spix, sb * (mat.emissive * mat.emissiveStrength));
-                }
-            }
-            nT -= n;
-            continue;
-        }
-
-        // ---- B. refill idle lanes: new primaries in the lowest ranks, then the top of the wave's stack --------------
-        uint32_t refilled = 0;
-        if (idle >= (stalled ? 1u : A.refill) && (sp > 0u || more)) {
-            const uint32_t take = sp < idle ? sp : idle;
-            uint32_t got = 0, pbase = 0;
-            if (more && take < idle) {
-                const uint32_t want = idle - take;
-                if (A.xcdBands) {
-                    // one band of the frame per XCD: the rays of neighbouring pixels walk the same part of the BVH, so an
-                    // XCD's L2 holds an eighth of what the frame's front touches instead of all of it.  A dry band stays
-                    // dry (its counter only grows), so a wave moves on through the bands once and is done after eight.
-                    while (more) {
-                        const uint32_t lo = curBand * bandLen, hi = lo + bandLen < A.npix ? lo + bandLen : A.npix;
-                        if (lane == 0) pbase = atomicAdd(A.pixCounter + curBand * 8u, want);
-                        pbase = __builtin_amdgcn_readfirstlane(pbase);
-                        const uint32_t len = hi > lo ? hi - lo : 0u;
-                        got = pbase < len ? (len - pbase < want ? len - pbase : want) : 0u;
-                        pbase += lo;
-                        if (got) break;
-                        curBand = (curBand + 1u) & 7u;
-                        if (++bandsDry == 8u) more = false;
-                    }
-                } else {
-                    if (lane == 0) pbase = atomicAdd(A.pixCounter, want);
-                    pbase = __builtin_amdgcn_readfirstlane(pbase);
-                    got = pbase < A.npix ? (A.npix - pbase < want ? A.npix - pbase : want) : 0u;
-                    if (got < want) more = false;
-                }
-            }
-            sp -= take;
-            refilled = take + got;
-#if !defined(MIPT_EXP_CLASSCOUNT) && !defined(MIPT_EXP_NH0COUNT)
-            MIPT_PROF(pf[10]++; pf[11] += take + got;)
-#endif
-            if (!active) {
-                const uint32_t rank = (uint32_t)__popcll(~actMask & below);
-                if (rank < got + take) {
-                    if (rank < got) {
-                        pix = A.pix0 + pbase + rank; node = 1; beta = mk3(1.f, 1.f, 1.f);
-                        if (A.band.pixels) pix = band_pixel(A.band, pix);
-                        gen_primary(A.F, pix, o, d, s0);
-                        if (A.alphaOne) A.sample[(size_t)pix * 4 + 3] = 1.f;
-                    } else {
-                        const uint32_t e = sp + (rank - got);
-                        float4 ra = stack_load(qa + e), rb = stack_load(qb + e), rc = stack_load(qc + e);
-                        o = xyz(ra); d = mk3(ra.w, rb.x, rb.y); beta = mk3(rb.z, rb.w, rc.x);
-                        pix = __float_as_uint(rc.y); node = __float_as_uint(rc.z); s0 = __float_as_uint(rc.w);
-                    }
-                    r = ray_pre<kShortRcp>(o, d);
-                    h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.ref = -1; h.tri = -1; h.front = false;
-                    tsp = 0;
-                    if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, kTerm); else MIPT_STACK_PUSH(lstk, deep, tsp, kTerm);
-                    cur = 0;
-                    if constexpr (emitFirst) if ((32u - (uint32_t)__clz((int)node)) >= A.F.maxDepth) {         // last level: the emitters' tree first
-                        if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, 0u); else MIPT_STACK_PUSH(lstk, deep, tsp, 0u);
-                        cur = A.S.emitRoot;
-                    }
-                    active = true;
-                    traced++;
-                    if constexpr (NEE) if (pix & kShadowBit) { shadowTraced++; h.t = __uint_as_float(node); }    // stops short of the emitter
-
-                    if (A.pixelRays) atomicAdd(A.pixelRays + (pix & (NEE ? kPixMask : 0xFFFFFFFFu)), 1u);
-                }
-            }
-        }
-
-        // ---- C. done when nothing is in flight, parked, stacked or left in the frame --------------------------------
-        const unsigned long long roundActive = MIPT_BALLOT(active);
-        const uint32_t nActive = (uint32_t)__popcll(roundActive);
-        if (nActive == 0u) {
-            if (nF + nT == 0u) break;
-            if (stalled) {          // nothing in flight and no room to shade into: a stack smaller than one record's children
-                if (lane == 0) atomicOr(A.stats + 39, 1ull);
-                if (nF || !lvl) nF -= nF < 64u ? nF : 64u; else nT -= nT < 64u ? nT : 64u;       // (level-sorted mode: both ends hold full records)
-            }
-            continue;
-        }
-
-        // ---- D. one traversal round: descend to the next leaf, test it, park the rays that have terminated ----------
-        MIPT_PROF(uint32_t myNodes = 0; uint32_t myTris = 0;)
-#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_NH0COUNT)
-        uint32_t myNh0 = 0, myNh1 = 0;
-#endif
-        // The node loop is wave-uniform: every lane stays in it and the visit runs under `go`.  It ends when fewer than
-        // minDescend lanes are still at inner nodes -- those resume next round, after the others' leaves have been
-        // tested and terminated rays replaced -- which bounds the tail of the loop (profiles/r1/lane_profile_*.log).
-        // minDescend = 1 is the classic while-while.
-        const uint32_t minDescend = A.minDescend < (nActive + 1u) / 2u ? A.minDescend : (nActive + 1u) / 2u;   // thin waves: scale down
-        // LDS-resident scenes: while too few rays have ended for a refill to follow, the wave goes round the node loop and
-        // the leaf test again before it parks anybody (Cornell +2.7 %; on the 4-wide kernels the extra loop level costs
-        // registers and 9-13 %: profiles/r2/exp_subround.log)
-        bool again;
-        do {
-        bool firstVisit = true;                 // every round makes progress: the first visit is unconditional
-        while (true) {
-            const bool go = active && !(cur & kLeaf);
-            // ballot of the compare itself, masked with the round's active mask on the scalar side (a ballot of the
-            // combined bool costs a v_cndmask + v_cmp_ne per iteration)
-            const uint32_t nGo = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)cur >= 0) & roundActive);
-            if (nGo == 0u || (!firstVisit && nGo < minDescend)) break;
-            firstVisit = false;
-            if (go) {
-                MIPT_PROF(myNodes++;)
-                float4 n0, n1, n2, n3;
-#ifdef MIPT_EXP_PAIR
-                load_node<LDS_SCENE>(ldsNodes, A.S.nodes2, cur, n0, n1, n2, n3);       // (nodes2: leaf references count in pairs)
-#else
-                load_node<LDS_SCENE>(ldsNodes, A.S.nodes, cur, n0, n1, n2, n3);
-#endif
-                if constexpr (WIDE) {
-                    // keep the four loads of the node together: without the child references in the hit test the
-                    // compiler sinks their load behind it, a second dependent round trip per visit
-                    asm volatile("" : "+v"(n3.w));
-#ifndef MIPT_EXP_BRANCHY_VISIT
-                    // The entry a miss would pop is fetched now, beside the node: its LDS latency hides behind the node's,
-                    // and what follows the visit needs no branch -- push and pop are one rule.  While the three slots above
-                    // the top are inside the LDS part of the stack (tsp <= kLdsStack - 3, all but unusually deep paths) they
-                    // are written unconditionally: slot j gets s[nh-1-j] (farthest deepest, second-nearest on top), what
-                    // lands above the new top is never read, and with no child hit the new top is one lower and the next
-                    // node is the entry fetched here.
-                    const bool shallow = tsp <= kLdsStack - 3;
-                    uint32_t popped = kTerm;
-                    if (shallow) popped = lstk[(tsp - 1) * kBlock];        // (tsp >= 1: the sentinel is never popped by a visit)
-#endif
-                    uint32_t s0_, s1_, s2_, s3_;
-                    const int nh = wide_visit(r, n0, n1, n2, n3, h.t, s0_, s1_, s2_, s3_);
-#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_NH0COUNT)
-                    myNh0 += nh == 0 ? 1u : 0u; myNh1 += nh == 1 ? 1u : 0u;      // (take the refill counters' slots: stats[18], stats[19])
-#endif
-#ifndef MIPT_EXP_BRANCHY_VISIT
-                    if (shallow) {
-                        const uint32_t a0 = nh == 4 ? s3_ : (nh == 3 ? s2_ : s1_);
-                        const uint32_t a1 = nh == 4 ? s2_ : s1_;
-                        uint32_t* const top = lstk + tsp * kBlock;
-                        top[0] = a0; top[kBlock] = a1; top[2 * kBlock] = s1_;
-                        tsp += nh - 1;
-                        cur = nh ? s0_ : popped;
-                    } else
-#endif
-                    if (nh == 0) { MIPT_STACK_POP(lstk, deep, tsp, cur); }
-                    else {
-                        if (tsp <= kLdsStack - 3) {
-                            // all three slots above the top are in LDS: write them without a branch per entry.  Slot j gets
-                            // s[nh-1-j] (farthest deepest, second-nearest on top); what lands above the new top is never read.
-                            const uint32_t a0 = nh == 4 ? s3_ : (nh == 3 ? s2_ : s1_);
-                            const uint32_t a1 = nh == 4 ? s2_ : s1_;
-                            uint32_t* const top = lstk + tsp * kBlock;
-                            top[0] = a0; top[kBlock] = a1; top[2 * kBlock] = s1_;
-                            tsp += nh - 1;
-                        } else
-                        {
-                            if (nh > 3) MIPT_STACK_PUSH(lstk, deep, tsp, s3_);
-                            if (nh > 2) MIPT_STACK_PUSH(lstk, deep, tsp, s2_);
-                            if (nh > 1) MIPT_STACK_PUSH(lstk, deep, tsp, s1_);
-                        }
-                        cur = s0_;
-                    }
-                } else {
-                    float t0, t1;
-                    uint32_t popped = kTerm;
-                    if constexpr (LDS_SCENE) popped = lstk[(tsp - 1) * kBlock];       // what a miss pops, fetched beside the node
-                    bool h0 = slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, h.t, t0);
-                    bool h1 = slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, h.t, t1);
-                    uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
-                    if constexpr (LDS_SCENE) {
-                        // push and pop as one branch-free rule (the LDS stack has one spare entry above the builder's bound, so
-                        // the unconditional store never leaves it): the far child goes above the top, and is kept only when
-                        // both children are hit; with no child hit the next node is the entry fetched above
-                        // (written so that the decisions stay lane masks in scalar registers: no 0/1 values in VGPRs)
-                        const bool nearIs1 = h1 & (!h0 | (t1 < t0));
-                        const uint32_t first = nearIs1 ? c1 : c0, second = nearIs1 ? c0 : c1;
-                        lstk[tsp * kBlock] = second;
-                        tsp = (tsp - 1) + ((h0 && h1) ? 1 : 0);          // two add-with-carry on the lane masks
-                        tsp += (h0 || h1) ? 1 : 0;
-                        cur = (h0 || h1) ? first : popped;
-                    } else
-                    if (h0 || h1) {
-                        uint32_t first = h0 ? c0 : c1;
-                        if (h0 && h1) {
-                            uint32_t second = c1;
-                            if (t1 < t0) { first = c1; second = c0; }
-                            if constexpr (LDS_SCENE) MIPT_STACK_PUSH_L(lstk, tsp, second); else MIPT_STACK_PUSH(lstk, deep, tsp, second);
-                        }
-                        cur = first;
-                    } else {
-                        if constexpr (LDS_SCENE) MIPT_STACK_POP_L(lstk, tsp, cur); else MIPT_STACK_POP(lstk, deep, tsp, cur);
-                    }
-                }
-            }
-        }
-        // (a bounded-tail loop over triangles or over whole leaves -- lanes that finish a leaf pop and go on testing while
-        // their neighbours work through longer leaves -- raised the leaf phase's lane utilisation but cost 2-4 % overall:
-        // profiles/r2/exp_rejected_variants.log)
-        if (active) {
-            if ((cur & kLeaf) && cur != kTerm) {
-                uint32_t cnt = (cur >> 27) & 0xFu, first = cur & 0x07FFFFFFu;
-#ifdef MIPT_EXP_PAIR
-                MIPT_PROF(myTris = LDS_SCENE ? cnt : (cnt + 1u) >> 1;)
-                // Measured and not adopted (profiles/r3/exp_pair_leaf.log): two triangles per leaf-loop iteration with packed
-                // fp32 arithmetic.  Bit-identical hits, 45 % fewer leaf-loop iterations and instructions, no gain.
-                if constexpr (!LDS_SCENE) {
-                    // two triangles per iteration from the pair layout (first = pair index; an odd leaf ends in a pad)
-                    for (uint32_t p = first; p < first + ((cnt + 1u) >> 1); p++) {
-                        const float4* T = A.S.refs2 + (size_t)p * 6;
-                        float4 q0 = T[0], q1 = T[1], q2 = T[2], q3 = T[3], q4 = T[4], q5 = T[5];
-                        asm volatile("" : "+v"(q0.x));        // all six loads of the record at once
-                        v3p v0, e1, e2;
-                        v0.x = pk(q0.x, q0.y); v0.y = pk(q0.z, q0.w); v0.z = pk(q1.x, q1.y);
-                        e1.x = pk(q2.x, q2.y); e1.y = pk(q2.z, q2.w); e1.z = pk(q3.x, q3.y);
-                        e2.x = pk(q4.x, q4.y); e2.y = pk(q4.z, q4.w); e2.z = pk(q5.x, q5.y);
-                        const PairTest r2 = mt_pair(o, d, v0, e1, e2);
-                        const int ida = (int)__float_as_uint(q1.z), idb = (int)__float_as_uint(q1.w);
-                        if (mt_accept(r2.det.x, r2.t.x, r2.u.x, r2.v.x, r2.uv.x, h.t, ida, h.tri)) {
-                            h.t = r2.t.x; h.v = r2.v.x; h.front = r2.det.x > 0; h.tri = ida;
-                            h.u = __uint_as_float(__float_as_uint(r2.u.x) | (__float_as_uint(q3.z) << 30));     // flags bit 1 -> sign bit
-                        }
-                        if (mt_accept(r2.det.y, r2.t.y, r2.u.y, r2.v.y, r2.uv.y, h.t, idb, h.tri)) {
-                            h.t = r2.t.y; h.v = r2.v.y; h.front = r2.det.y > 0; h.tri = idb;
-                            h.u = __uint_as_float(__float_as_uint(r2.u.y) | (__float_as_uint(q3.w) << 30));
-                        }
-                    }
-                } else
-#else
-                MIPT_PROF(myTris = cnt;)
-#endif
-                for (uint32_t i = first; i < first + cnt; i++) {
-                    float4 a, b, c;
-                    load_ref<LDS_SCENE>(ldsRefs, A.S.refs, i, a, b, c);
-                    // all three loads of the record at once (the compiler sinks the vertex behind the determinant test)
-                    if constexpr (!LDS_SCENE) asm volatile("" : "+v"(a.x));
-                    int id = (int)__float_as_uint(a.w);
-                    // mt_test without its early returns: the same values and the same decisions as one flat expression.  In a
-                    // wave some lane nearly always passes each of the early tests, so the returns skipped nothing and cost a
-                    // nest of exec-mask branches (~40 scalar instructions per test): Cornell +6.1 %, Default +4.6 %, grid +2.6 %
-                    // (profiles/r3/exp_flat_leaf.log)
-                    {
-                        const v3 v0_ = xyz(a), e1_ = xyz(b), e2_ = xyz(c);
-                        const v3 pvec = cross3(d, e2_);
-                        const float det = dot3(e1_, pvec);
-                        const float inv = rcp_newton<1>(det);
-                        const v3 tvec = o - v0_;
-                        const float uu = dot3(tvec, pvec) * inv;
-                        const v3 qvec = cross3(tvec, e1_);
-                        const float vv = dot3(d, qvec) * inv;
-                        const float tt = dot3(e2_, qvec) * inv;
-                        if (mt_accept(det, tt, uu, vv, uu + vv, h.t, id, h.tri)) {
-                            h.t = tt; h.v = vv; h.front = det > 0; h.tri = id;
-                            h.u = __uint_as_float(__float_as_uint(uu) | (__float_as_uint(c.w) << 30));     // flags bit 1 -> sign bit
-                        }
-                    }
-                }
-                // (fetching the popped entry ahead of the triangles, as the node visits do, measured -0.5 % here: exp_flat_visit.log)
-                if constexpr (LDS_SCENE) MIPT_STACK_POP_L(lstk, tsp, cur); else MIPT_STACK_POP(lstk, deep, tsp, cur);
-                if constexpr (NEE) if ((pix & kShadowBit) && h.tri >= 0) cur = kTerm;      // occlusion ray: any hit ends it
-                // no emitting mesh in the scene: a last-level ray adds nothing if it hits anything, so its first hit ends it
-                // (its level is recomputed from the node id: cheaper than a register held through the traversal)
-                if constexpr (!emitFirst) { if (A.S.emissiveMeshes == 0u) { if (h.tri >= 0 && (32u - (uint32_t)__clz((int)node)) >= A.F.maxDepth) cur = kTerm; } }
-                else {
-                    // emitters first (see above): a last-level ray ends at the first hit on something that does not emit; under a
-                    // black sky it also ends when the emitters' tree is exhausted without a hit (the entry just popped is the main
-                    // root, reference 0, which sits on no other ray's stack) or, having slipped into the main tree, at its next leaf
-                    if ((32u - (uint32_t)__clz((int)node)) >= A.F.maxDepth) {
-                        const bool emits = (__float_as_uint(h.u) >> 31) != 0u;
-                        const bool over = h.tri >= 0 ? !emits : (skyBlack && (cur == 0u || (cnt != 0u && first < A.S.nRefsMain)));      // (cnt 0: an empty slot's reference, not a leaf of the main tree)
-                        if (over) cur = kTerm;
-                    }
-                }
-            }
-        }
-        again = false;
-        if constexpr (LDS_SCENE && !NEE) {      // (the light-sampling variants are short of registers as it is)
-            const uint32_t nFinNow = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cur == kTerm) & roundActive);
-            again = nFinNow + (64u - nActive) < A.refill && nFinNow < nActive;
-        }
-        } while (again);
-        MIPT_PROF(pf[0]++; pf[1] += (uint32_t)__popcll(MIPT_BALLOT(active)); pf[2] += wave_max_u32(myNodes); pf[3] += wave_sum_u32(myNodes);
-                  pf[4] += wave_max_u32(myTris); pf[5] += wave_sum_u32(myTris);)
-#if defined(MIPT_LANE_PROFILE) && defined(MIPT_EXP_NH0COUNT)
-        pf[10] += wave_sum_u32(myNh0); pf[11] += wave_sum_u32(myNh1);
-#endif
-        bool fin = active && cur == kTerm;
-        unsigned long long fm = MIPT_BALLOT(fin);
-        // the one state a stalled wave cannot leave by itself (see A1): no lane refilled, none still traversing, and -- checked
-        // below -- none of the finished ones able to park or retire
-        const bool stuck = stalled && refilled == 0u && (fm == roundActive);
-        uint32_t moved = 0;
-        if (fm) {
-            const uint32_t level = 31u - (uint32_t)__clz((int)node);             // root = 1 -> level 0
-            const bool term = h.tri < 0 || level + 1 >= A.F.maxDepth              // children would have ttl 0 (CUDATracerProg.cu:433)
-                              || (NEE && (pix & kShadowBit));
-            if (fin && term) {
-                const bool shadow = NEE && (pix & kShadowBit);
-                const bool dead = h.tri < 0 ? (!shadow && (skyBlack || (NEE && (pix & kNoEnvBit))))
-                                            : (shadow || !(__float_as_uint(h.u) >> 31) || (NEE && (pix & kNoEmitBit)));
-                if (dead) { active = false; fin = false; }
-                else if (lvl) {
-                    // level-sorted mode (A1): a terminal record that is not dead is a last-level ray whose closest hit emits (the sky
-                    // is black).  There are few of them; its emission is added here, so that the queue's top end is free for the
-                    // records whose children will be at the last level
-                    const uint32_t mesh = __float_as_uint(A.S.shade[(size_t)h.tri * 3].w);
-                    Material mat = load_material(A.S, mesh);
-                    add_sample(A.sample, pix, beta * (mat.emissive * mat.emissiveStrength));
-                    active = false; fin = false;
-                }
-            }
-            moved = (uint32_t)__popcll(fm);
-            fm = MIPT_BALLOT(fin);
-            moved -= (uint32_t)__popcll(fm);          // retired on the spot
-            // no room: stay terminated-but-unparked until the queue has been drained
-            fin = fin && nF + nT + (uint32_t)__popcll(fm & below) < (uint32_t)kSqCap;
-            // which end of the queue: terminal records at the top -- or, in level-sorted mode, the records whose children will be at the last level
-            const bool top = lvl ? level + 2u >= A.F.maxDepth : term;
-            const unsigned long long mF = MIPT_BALLOT(fin && !top), mT = MIPT_BALLOT(fin && top);
-            if (fin) {
-                const uint32_t e = top ? (uint32_t)kSqCap - 1u - (nT + (uint32_t)__popcll(mT & below)) : nF + (uint32_t)__popcll(mF & below);
-                v3 P = o + d * h.t;                                   // tail of NearestIntersectSubset (:294)
-                sq[0 * kSqCap + e] = P.x; sq[1 * kSqCap + e] = P.y; sq[2 * kSqCap + e] = P.z;
-                sq[3 * kSqCap + e] = d.x; sq[4 * kSqCap + e] = d.y; sq[5 * kSqCap + e] = d.z;
-                sq[6 * kSqCap + e] = beta.x; sq[7 * kSqCap + e] = beta.y; sq[8 * kSqCap + e] = beta.z;
-                sqi[9 * kSqCap + e] = pix; sqi[10 * kSqCap + e] = node; sqi[11 * kSqCap + e] = s0;
-                sq[12 * kSqCap + e] = __builtin_fabsf(h.u); sq[13 * kSqCap + e] = h.v;
-                sqi[14 * kSqCap + e] = h.tri < 0 ? 0xFFFFFFFFu : ((uint32_t)h.tri | (h.front ? 0x80000000u : 0u));
-                active = false;
-            }
-            nF += (uint32_t)__popcll(mF); nT += (uint32_t)__popcll(mT);
-            moved += (uint32_t)__popcll(mF | mT);
-        }
-        if (stuck && moved == 0u) {       // overflow: the children of one batch are lost, the host reports it, nothing is written past the stack
-            if (lane == 0) atomicOr(A.stats + 39, 1ull);
-            if (nF || !lvl) nF -= nF < 64u ? nF : 64u; else nT -= nT < 64u ? nT : 64u;
-        }
-    }
-    // one counter update per wave
-    for (int sh = 32; sh > 0; sh >>= 1) traced += __shfl_down(traced, sh);
-    if (lane == 0 && traced) atomicAdd(A.stats, (unsigned long long)traced);
-    if (lane == 0 && nShort) atomicAdd(A.stats + 36, (unsigned long long)nShort);
-    if constexpr (NEE) {
-        for (int sh = 32; sh > 0; sh >>= 1) shadowTraced += __shfl_down(shadowTraced, sh);
-        if (lane == 0 && shadowTraced) atomicAdd(A.stats + 38, (unsigned long long)shadowTraced);
-    }
-    MIPT_PROF(if (lane == 0) for (int k = 0; k < 12; k++) atomicAdd(A.stats + 8 + k, pf[k]);)
+    // the body is wavestack_kernel.inc, once per residence of the scene (the reason is at its MIPT_BATCHES_BEGIN)
+    if constexpr (LDS_SCENE)
+#define MIPT_WS_LDS_SCENE 1
+#include "wavestack_kernel.inc"
+#undef MIPT_WS_LDS_SCENE
+    else
+#define MIPT_WS_LDS_SCENE 0
+#include "wavestack_kernel.inc"
+#undef MIPT_WS_LDS_SCENE
 }
 
 bool wavestack_scene_in_lds(const SceneDev& S) {

@@ -13,7 +13,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def source_sha16():      # same hash as bench.py: the figures are attached only to the sources they were measured on
     h = hashlib.sha256()
-    for f in ("kernels.hip", "kernels.h", "device_math.h", "api.hip", "bvh_builder.cpp"):
+    for f in ("kernels.hip", "wavestack_kernel.inc", "kernels.h", "device_math.h", "api.hip", "bvh_builder.cpp"):
         h.update(open(os.path.join(ROOT, "cudapathtracer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 out = {"_meta": {"source_sha16": source_sha16(), "collected": "rocprofv3 --pmc passes of `bench.py --workload W --steps 2 --warmup 1`, scripts/pmc_passes.sh, " + time.strftime("%Y-%m-%d")}}
