@@ -711,8 +711,10 @@ MIPT_DEV uint32_t wave_sum_u32(uint32_t v) { for (int s = 32; s > 0; s >>= 1) v 
 // threads: +0.5 %).  A one-wave block takes a sixteenth of the CU's LDS (3 KiB stack + 7 KiB shade queue).  LDS-resident
 // scenes keep four waves per block: they share the block's copy of the scene.
 template <bool LDS_SCENE> struct WaveStackBlock { static constexpr int value = LDS_SCENE ? 256 : 64; };
-// 4 waves per SIMD at the 128-VGPR cap (4-5 spills outside the hot loops).  Three with the ~145 VGPRs the compiler would
-// like (no spills) run 0.85x; five at 96 VGPRs and 32 KiB of LDS per 256 threads spill 35-40 registers, 0.6-0.7x.
+// 4 waves per SIMD: 103-113 VGPRs without light sampling since the device code is built without the SLP vectoriser (Makefile),
+// 128 with it and for the light-sampling variants.  Measured before that: three waves with the ~145 VGPRs the compiler then
+// wanted run 0.85x, five at 96 VGPRs spilt 35-40 registers, 0.6-0.7x; after it: five waves (96 VGPRs, 4-5 spills, 8 KiB of LDS
+// per wave) Default +0.6 %, grid -4.5 % (profiles/r3/exp_codegen_flags.log).  Sixteen waves of 10 KiB fill the CU's LDS.
 template <bool LDS_SCENE, bool WIDE, bool NEE, bool PBS = false, bool EMIT = false>      // EMIT: the scene has an emitters' tree ("emitters first", below)
 __global__ void __launch_bounds__(WaveStackBlock<LDS_SCENE>::value, 4) k_wavestack(StackArgs A) {       // (hipcc: second argument = minimum waves per SIMD)
     // the body is wavestack_kernel.inc, once per residence of the scene (the reason is at its MIPT_BATCHES_BEGIN)
